@@ -1,0 +1,197 @@
+/*
+ * libmvoc_hip.so -- C ABI of the MI355X (gfx950) kernels behind MVOC's denoising hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes, is asynchronous on the HIP
+ * stream passed as `void* stream` (a hipStream_t), never allocates or frees device memory, never
+ * synchronises the device and keeps no pointer past return (graph-capture safe).  Return value: 0 on
+ * success, -1 invalid argument, -2 unsupported shape, -3 HIP error; text via mvoc_last_error()
+ * (thread-local).  The caller (PyTorch) owns all buffers.  fp16 = IEEE binary16.
+ *
+ * Canonical activation layout in HBM: channels-last "tokens" [B, F, H*W, C] (row-major, C contiguous),
+ * i.e. a [rows = B*F*H*W, C] matrix.  Spatial ops see it as [B*F images][H*W][C]; temporal ops walk
+ * the frame axis with row stride H*W.  The reference's NCHW <-> token <-> frame-major permute copies
+ * (pnp_utils.py:185-189, 207-213, 434-437, 502-506) do not exist here.
+ *
+ * Each entry names the reference interface it replaces (paths relative to the reference checkout).
+ */
+#ifndef MVOC_HIP_H
+#define MVOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVOC_VERSION 100
+
+int mvoc_version(void);
+const char* mvoc_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM on MFMA (fp16 in, fp32 accumulate, fp16 out):  out[m, n] = epi( sum_k A(m,k) * W[n,k] )
+ * Replaces every F.linear / F.conv2d(3x3, 1x1) / F.conv3d((3,1,1)) on the path:
+ *   F.linear  pnp_utils.py:191,206,438,505,604-612,692,759-767,870; pipeline_i2vgen_xl.py:188,193,231
+ *   conv2d    pnp_utils.py:939,968,1013 (ResnetBlock2D), :1112 (conv_out); pipeline_i2vgen_xl.py:284
+ *   conv3d    pnp_utils.py:1048-1051 (TemporalConvLayer)
+ * ------------------------------------------------------------------------------------------- */
+enum { MVOC_A_PLAIN = 0, MVOC_A_CONV3X3 = 1, MVOC_A_TEMPORAL3 = 2 };
+enum { MVOC_ACT_NONE = 0, MVOC_ACT_GEGLU = 1, MVOC_ACT_SILU = 2, MVOC_ACT_GELU = 3 };
+
+typedef struct mvoc_gemm_desc {
+  /* operands */
+  const void* a;        /* activation source 1 (fp16) */
+  const void* a2;       /* optional source 2 for a channel-concat input (cat([x, skip], dim=1)); NULL if none */
+  const void* w;        /* weights [n_pad][k] fp16, k contiguous; for conv k = tap*cin + c (tap-major) */
+  void* out;            /* [m][ldo] fp16 */
+  const void* bias;     /* [n] fp16 or NULL (GEGLU: packed like w rows) */
+  const void* rowadd;   /* optional [m / rowadd_div][ld_rowadd] fp16 added per output row (time embedding) */
+  const void* resid;    /* optional residual [m][ldr] fp16 added after bias/act */
+  int64_t m, n, k;      /* n = rows of w (multiple of 32); k multiple of 32 */
+  int32_t n_store;      /* columns actually written (<= n; GEGLU: n/2) */
+  int32_t ldo, ldr, ld_rowadd, rowadd_div;
+  int32_t a_mode;       /* MVOC_A_* */
+  int32_t lda, lda2;    /* row strides (elements) of a / a2 */
+  int32_t c1;           /* channels taken from `a` per tap (rest from a2); == cin when a2 == NULL */
+  int32_t cin;          /* conv / temporal: channels per tap (c1 + c2); plain: == k */
+  /* conv3x3 (pad 1): output pixel grid [nimg][hout][wout]; source image [hsrc][wsrc]; if upsample != 0 the
+   * conv runs on the nearest-upsampled [hup][wup] view of the source (Upsample2D folded into the gather) */
+  int32_t nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
+  /* temporal3 (pad 1 over frames): rows are [nvid][frames][hw] */
+  int32_t frames, hw;
+  int32_t act;          /* MVOC_ACT_* */
+  int32_t tile;         /* 0 = auto; otherwise force a tile config id (tuning) */
+} mvoc_gemm_desc;
+
+int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention, head_dim 64, softmax(Q K^T / 8) V, no mask (F.scaled_dot_product_attention at
+ * pnp_utils.py:684-686, 862-864 and the stock AttnProcessor2_0 sites).
+ * q/k/v/out element (b, t, h, d) lives at base + b*bs + t*ts + h*64 + d  (elements).
+ * kv batch index = b / kv_bdiv (cross-attention context shared by all frames of a sample).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mvoc_attn_desc {
+  const void *q, *k, *v;
+  void* out;
+  int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int32_t nbatch, heads, tq, tk, kv_bdiv;
+} mvoc_attn_desc;
+
+/* spatial self-attention and image/text cross-attention (flash-style, K/V tiles LDS-staged) */
+int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream);
+/* temporal self-attention: one sequence per (sample, pixel), tq == tk == frames <= 32; "t" walks frames
+ * (ts = H*W*C for the canonical layout), "b" walks sample*pixel via (b / hw)*bs + (b % hw)*ps */
+typedef struct mvoc_tattn_desc {
+  const void *q, *k, *v;
+  void* out;
+  int64_t q_bs, q_ps, q_ts, k_bs, k_ps, k_ts, v_bs, v_ps, v_ts, o_bs, o_ps, o_ts;
+  int32_t nsample, hw, heads, frames;
+} mvoc_tattn_desc;
+int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) on channels-last rows; F.group_norm + F.silu at pnp_utils.py:909-910, 953-965 (4-D,
+ * statistics per image), :188 and TemporalConvLayer (5-D, statistics per video), :430, and
+ * pipeline_i2vgen_xl.py:351-352.  Input may be a 2-source channel concat.  Deterministic (no atomics).
+ *   workspace floats: nsample * (nchunk*3 + 2) * groups  -> mvoc_groupnorm_workspace_bytes
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mvoc_gn_desc {
+  const void* x;        /* [nsample*rows_per_sample][c1] fp16 */
+  const void* x2;       /* optional second source [..][c - c1] */
+  const void* gamma;    /* [c] fp16 */
+  const void* beta;     /* [c] fp16 */
+  void* out;            /* [nsample*rows_per_sample][c] fp16 */
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t nsample, rows_per_sample, c, c1, groups, silu;
+  float eps;
+} mvoc_gn_desc;
+size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups);
+int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream);
+
+/* LayerNorm over the last dim (F.layer_norm at pnp_utils.py:250,296,322), eps 1e-5, affine */
+int mvoc_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int64_t rows, int32_t c,
+                       float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PnP masked blend + scatter.  For every (frame f, pixel p, channel c):
+ *     inj = base;  for j in objects:  inj = inj*(1-m_j) + obj_j*m_j     (three fp16-rounded ops, in this order)
+ *     chunk[n-2] = chunk[n-1] = inj
+ * with chunks positional [bg, obj_1..obj_k, uncond, cond] (k <= 4), base = chunk n-1 (or chunk 0 when
+ * base_chunk0 != 0), m_j = mask_j[f, nearest(p)] (fp16 values: exact {0,1} for bool masks, k/255 for soft masks).
+ * BIT-EXACT against the reference arithmetic (not a select: -0.0 / inf / NaN propagate as in x*(1-m)+y*m).
+ *   tokens: element (chunk, f, p, c) at x + chunk*chunk_stride + f*f_stride + p*p_stride + c   (c contiguous)
+ *           -> spatial Q/K [5F, HW, C]   (pnp_utils.py:624-672):  chunk_stride=F*HW*C, f_stride=HW*C, p_stride=C
+ *           -> temporal Q/K [5HW, F, C]  (pnp_utils.py:778-850):  chunk_stride=HW*F*C, f_stride=C,    p_stride=F*C
+ *           -> canonical [5, F, HW, C] features (resnet / temporal-conv / conv_out injection)
+ *   nchw:   x [5F, C, H, W] (pnp_utils.py:970-1004, 1059-1082, 1114-1146): p contiguous
+ * masks: [nobj][F][mh][mw] fp16, nearest-resized to (H, W) like F.interpolate(mode='nearest').
+ * Up to two tensors (Q and K) are processed by one launch (x2 may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mvoc_pnp_desc {
+  void* x;
+  void* x2;
+  const void* masks;
+  int64_t chunk_stride, f_stride, p_stride;
+  int32_t nobj, frames, height, width, channels, mask_h, mask_w, base_chunk0;
+} mvoc_pnp_desc;
+int mvoc_pnp_blend_scatter_tokens(const mvoc_pnp_desc* d, void* stream);
+int mvoc_pnp_blend_scatter_nchw(const mvoc_pnp_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loop glue on [B,4,F,h,w] fp16 latents, BIT-EXACT vs the reference's eager fp16 op chain.
+ *   cfg + DDIM / inverse-DDIM update (pipeline_i2vgen_xl.py:1187-1199, 1713-1731, 1967-1984;
+ *   diffusers DDIMScheduler.step / DDIMInverseScheduler.step, v_prediction, eta = 0):
+ *     v   = uncond + g*(cond-uncond)            (skipped when uncond == NULL: v = cond)
+ *     x0  = sa*x - sb*v ; eps = sa*v + sb*x ; out = sp*x0 + sq*eps
+ *   coef = {sa, sb, sp, sq, g} fp32 on the DEVICE (so a captured graph can be replayed per step)
+ * ------------------------------------------------------------------------------------------- */
+int mvoc_ddim_step_f16(const void* x, const void* v_uncond, const void* v_cond, const float* coef_dev, void* out,
+                       int64_t n, void* stream);
+/* latent noise fusion (pipeline_i2vgen_xl.py:1644-1663); objs/masks: nobj device pointers packed in arrays
+ * of contiguous [n] fp16 tensors: obj[j] at objs + j*n, mask[j] at masks + j*n */
+int mvoc_latent_fusion_f16(const void* latents, const void* bg, const void* objs, const void* masks, void* out,
+                           int32_t nobj, int64_t n, double mix_ratio, int32_t obj_random_noise_fusion, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stem / small ops (pipeline_i2vgen_xl.py:166-290, 351-357).
+ * ------------------------------------------------------------------------------------------- */
+/* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift 0): out[b] = [cos | sin] rounded to fp16; t fp32 on device */
+int mvoc_timestep_embedding_f16(const float* t_dev, int32_t nb, int32_t dim, void* out, void* stream);
+/* y = silu(x) / gelu(x) elementwise, fp16 */
+int mvoc_act_f16(const void* x, void* out, int64_t n, int32_t act, void* stream);
+/* out = a + b (fp16, rounded once) */
+int mvoc_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* direct 3x3 conv (pad 1) on channels-last images for tiny channel counts; w [cout][3][3][cin] fp16 */
+int mvoc_conv3x3_small_f16(const void* x, const void* w, const void* bias, void* out, int32_t nimg, int32_t h,
+                           int32_t wd, int32_t cin, int32_t cout, int32_t stride, int32_t silu, void* stream);
+/* AdaptiveAvgPool2d on channels-last images */
+int mvoc_adaptive_avgpool_f16(const void* x, void* out, int32_t nimg, int32_t h, int32_t w, int32_t c, int32_t oh,
+                              int32_t ow, void* stream);
+/* [B,C,F,h,w] (reference boundary layout) -> channels-last [B,F,h*w,ldo] at channel offset coff */
+int mvoc_ncfhw_to_tokens_f16(const void* x, void* out, int32_t b, int32_t c, int32_t f, int32_t hw, int32_t ldo,
+                             int32_t coff, void* stream);
+/* channels-last [B,F,h*w,ld] (first c channels) -> [B,C,F,h,w] */
+int mvoc_tokens_to_ncfhw_f16(const void* x, void* out, int32_t b, int32_t c, int32_t f, int32_t hw, int32_t ld,
+                             void* stream);
+/* I2VGenXLTransformerTemporalEncoder (dim 4, 2 heads x 4) fused: LN -> self-attn over frames (+res) -> FF(gelu)
+ * (+res) on x [B,F,hw,4] channels-last, written into out [B,F,hw,ldo] at channel offset coff.
+ * params: fp16 blob {ln_g[4], ln_b[4], wq[8][4], wk[8][4], wv[8][4], wo[4][8], bo[4], w1[16][4], b1[16], w2[4][16], b2[4]} */
+int mvoc_temporal_encoder4_f16(const void* x, const void* params, void* out, int32_t b, int32_t f, int32_t hw,
+                               int32_t ldo, int32_t coff, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).
+ * ------------------------------------------------------------------------------------------- */
+enum { MVOC_FAM_GEMM = 0, MVOC_FAM_FLASH = 1, MVOC_FAM_TATTN = 2, MVOC_FAM_GN = 3, MVOC_FAM_LN = 4, MVOC_FAM_PNP = 5,
+       MVOC_FAM_MISC = 6, MVOC_FAM_COUNT = 7 };
+int mvoc_prof_enable(int on);                  /* 1: bracket every launch with hipEvents (not capture-safe) */
+int mvoc_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_or_bytes_per_family);
+int mvoc_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVOC_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmvoc_hip.so (declared in include/mvoc_hip.h).
+
+The library is the product: importing this module fails loudly when it is missing -- there is no CPU or
+PyTorch fallback behind any op in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvoc_hip.so")
+
+A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
+FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "pnp", "misc")
+
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("a", vp), ("a2", vp), ("w", vp), ("out", vp), ("bias", vp), ("rowadd", vp), ("resid", vp),
+                ("m", i64), ("n", i64), ("k", i64), ("n_store", i32), ("ldo", i32), ("ldr", i32), ("ld_rowadd", i32),
+                ("rowadd_div", i32), ("a_mode", i32), ("lda", i32), ("lda2", i32), ("c1", i32), ("cin", i32),
+                ("nimg", i32), ("hout", i32), ("wout", i32), ("hsrc", i32), ("wsrc", i32), ("stride", i32),
+                ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp),
+                ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ts", i64), ("v_bs", i64), ("v_ts", i64),
+                ("o_bs", i64), ("o_ts", i64),
+                ("nbatch", i32), ("heads", i32), ("tq", i32), ("tk", i32), ("kv_bdiv", i32)]
+
+
+class TAttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp),
+                ("q_bs", i64), ("q_ps", i64), ("q_ts", i64), ("k_bs", i64), ("k_ps", i64), ("k_ts", i64),
+                ("v_bs", i64), ("v_ps", i64), ("v_ts", i64), ("o_bs", i64), ("o_ps", i64), ("o_ts", i64),
+                ("nsample", i32), ("hw", i32), ("heads", i32), ("frames", i32)]
+
+
+class GnDesc(C.Structure):
+    _fields_ = [("x", vp), ("x2", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("workspace", vp),
+                ("workspace_bytes", sz), ("nsample", i32), ("rows_per_sample", i32), ("c", i32), ("c1", i32),
+                ("groups", i32), ("silu", i32), ("eps", f32)]
+
+
+class PnpDesc(C.Structure):
+    _fields_ = [("x", vp), ("x2", vp), ("masks", vp), ("chunk_stride", i64), ("f_stride", i64), ("p_stride", i64),
+                ("nobj", i32), ("frames", i32), ("height", i32), ("width", i32), ("channels", i32), ("mask_h", i32),
+                ("mask_w", i32), ("base_chunk0", i32)]
+
+
+# every symbol include/mvoc_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mvoc_version": (i32, []),
+    "mvoc_last_error": (C.c_char_p, []),
+    "mvoc_gemm_f16": (i32, [C.POINTER(GemmDesc), vp]),
+    "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
+    "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
+    "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
+    "mvoc_layernorm_f16": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
+    "mvoc_pnp_blend_scatter_tokens": (i32, [C.POINTER(PnpDesc), vp]),
+    "mvoc_pnp_blend_scatter_nchw": (i32, [C.POINTER(PnpDesc), vp]),
+    "mvoc_ddim_step_f16": (i32, [vp, vp, vp, vp, vp, i64, vp]),
+    "mvoc_latent_fusion_f16": (i32, [vp, vp, vp, vp, vp, i32, i64, f64, i32, vp]),
+    "mvoc_timestep_embedding_f16": (i32, [vp, i32, i32, vp, vp]),
+    "mvoc_act_f16": (i32, [vp, vp, i64, i32, vp]),
+    "mvoc_add_f16": (i32, [vp, vp, vp, i64, vp]),
+    "mvoc_conv3x3_small_f16": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mvoc_adaptive_avgpool_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mvoc_ncfhw_to_tokens_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mvoc_tokens_to_ncfhw_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mvoc_temporal_encoder4_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mvoc_prof_enable": (i32, [i32]),
+    "mvoc_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
+    "mvoc_prof_reset": (i32, []),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m mvoc_amd.build` (hipcc --offload-arch=gfx950). "
+            "mvoc_amd has no CPU / PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"libmvoc_hip {what} failed ({rc}): {lib.mvoc_last_error().decode()}")

@@ -1,0 +1,60 @@
+"""Build libmvoc_hip.so (gfx950) in-tree with hipcc.  No CMake, no JIT cache: the .so sits next to the sources so
+it travels to the GPU box with the repo snapshot."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmvoc_hip.so")
+SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=on"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/mvoc_hip.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    stamp = LIB + ".stamp"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            failed = True
+            print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
+    if failed:
+        raise RuntimeError("libmvoc_hip.so: compilation failed")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,326 @@
+// Attention kernels for gfx950, head_dim 64, fp16 in/out, fp32 softmax + accumulate.
+//
+// flash_kernel  -- spatial self-attention (T up to 14400) and image/text cross-attention (145 keys):
+//   block = 4 waves, each wave owns 32 query rows (Q fragments live in registers for the whole kernel);
+//   K/V tiles of 64 keys are staged global -> registers -> LDS (loads of tile t+1 are in flight while tile t is
+//   computed).  Scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_f16 with K as the row operand),
+//   so each lane holds the scores of ONE query (col = lane&31) -> row max / row sum are in-lane plus one
+//   cross-half shuffle, and the fp16-packed P^T accumulator registers are directly the column operand of
+//   O^T = V^T P^T.  V is written to LDS transposed ([d][key]) with its keys permuted into exactly the k order
+//   the accumulator layout imposes (key = 32t + 16s + 8(j>>2) + 4h + (j&3) for element j of lane-half h), so the
+//   V^T fragment is one ds_read_b128.  LDS pitches/swizzles were chosen by exhaustive bank-conflict enumeration
+//   (K: pitch 144 B conflict-free reads; V^T: pitch 160 B + 16-byte-group XOR (d>>3): conflict-free b16 writes,
+//   2-way b128 reads).
+//
+// tattn_kernel  -- temporal self-attention: one wave per (sample, pixel, head); the sequence is the frame axis
+//   (<= 32 frames), rows are strided by H*W*C in the canonical layout so no [B*HW, F, C] copy is ever made.
+//   Same transposed-score scheme with a single 32x32 tile; V^T goes through a 4 KB wave-private LDS image.
+#include "common.h"
+
+namespace {
+
+constexpr int KPITCH = 144;
+constexpr int VPITCH = 160;
+
+struct AttnArgs {
+  const half_t *q, *k, *v;
+  half_t* out;
+  long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int nbatch, heads, tq, tk, kv_bdiv;
+  float scale_log2;
+};
+
+__device__ __forceinline__ int vt_slot_group(int key) {  // 16-byte group (8 slots) of a key inside its 32-key tile
+  return ((((key >> 5) * 2 + ((key >> 4) & 1)) * 2) + ((key >> 2) & 1));
+}
+__device__ __forceinline__ int vt_slot_elem(int key) { return ((key >> 3) & 1) * 4 + (key & 3); }
+
+__global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + 64 * VPITCH];
+  char* Ks = smem;
+  char* Vs = smem + 64 * KPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const half_t* qp = p.q + (long)b * p.q_bs + head * 64;
+  const int qrow = min(q0 + r, p.tq - 1);
+  half8_t qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
+
+  const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * 64;
+  const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * 64;
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int ntiles = (p.tk + 63) / 64;
+  half8_t kreg[2], vreg[2];
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int key = kt * 64 + (c >> 3), dc = c & 7;
+      kreg[i] = zero8;
+      vreg[i] = zero8;
+      if (key < p.tk) {
+        kreg[i] = *reinterpret_cast<const half8_t*>(kb + (long)key * p.k_ts + dc * 8);
+        vreg[i] = *reinterpret_cast<const half8_t*>(vb + (long)key * p.v_ts + dc * 8);
+      }
+    }
+  };
+  gload(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int key = c >> 3, dc = c & 7;
+      *reinterpret_cast<half8_t*>(Ks + key * KPITCH + dc * 16) = kreg[i];
+      const int g = vt_slot_group(key), j = vt_slot_elem(key);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = dc * 8 + e;
+        *reinterpret_cast<half_t*>(Vs + d * VPITCH + ((g ^ ((d >> 3) & 7)) * 16) + j * 2) = vreg[i][e];
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) gload(kt + 1);
+
+    // S^T = K Q^T : st[t][reg] = S[query r][key 32t + 8(reg>>2) + 4h + (reg&3)]
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (32 * t + r) * KPITCH + (16 * s + 8 * h) * 2);
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
+      }
+    }
+    const bool tail = (kt == ntiles - 1) && (p.tk & 63);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float sv = st[t][e] * p.scale_log2;
+        if (tail) {
+          const int key = kt * 64 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3);
+          if (key >= p.tk) sv = -INFINITY;
+        }
+        st[t][e] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = exp2f(mrun - mnew);
+    mrun = mnew;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = exp2f(st[t][e] - mnew);
+        st[t][e] = pv;
+        ps += pv;
+      }
+    lrun = lrun * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
+
+    // O^T += V^T P^T : accumulator registers 8s..8s+7 of tile t are the column operand of k-step (t, s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8_t pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (half_t)st[t][8 * s + j];
+        const int g = (t * 2 + s) * 2 + h;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d = 32 * dt + r;
+          const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + d * VPITCH + ((g ^ ((d >> 3) & 7)) * 16));
+          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+        }
+      }
+  }
+  const float ltot = lrun + __shfl_xor(lrun, 32);
+  const float inv = 1.0f / ltot;
+  if (q0 + r < p.tq) {
+    half_t* op = p.out + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][q * 4 + e] * inv);
+        *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct TAttnArgs {
+  const half_t *q, *k, *v;
+  half_t* out;
+  long q_bs, q_ps, q_ts, k_bs, k_ps, k_ts, v_bs, v_ps, v_ts, o_bs, o_ps, o_ts;
+  int nsample, hw, heads, frames;
+  long ntask;
+  float scale_log2;
+};
+
+constexpr int TVPITCH = 64;
+
+__global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 64 * TVPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  char* Vs = smem + wave * 64 * TVPITCH;
+  const long task = (long)blockIdx.x * 4 + wave;
+  const bool active = task < p.ntask;  // whole wave uniform
+  const long tk = active ? task : p.ntask - 1;
+  const int head = (int)(tk % p.heads);
+  const long bp = tk / p.heads;
+  const long smp = bp / p.hw, px = bp % p.hw;
+  const int F = p.frames;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  const half_t* qb = p.q + smp * p.q_bs + px * p.q_ps + head * 64;
+  const half_t* kb = p.k + smp * p.k_bs + px * p.k_ps + head * 64;
+  const half_t* vb = p.v + smp * p.v_bs + px * p.v_ps + head * 64;
+
+  // V: 32 frames x 8 chunks = 256 chunks, 4 per lane, transposed into the wave-private LDS image
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    const int key = c >> 3, dc = c & 7;
+    half8_t vr = zero8;
+    if (key < F) vr = *reinterpret_cast<const half8_t*>(vb + (long)key * p.v_ts + dc * 8);
+    const int g = (((key >> 4) & 1) * 2) + ((key >> 2) & 1), j = vt_slot_elem(key);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = dc * 8 + e;
+      *reinterpret_cast<half_t*>(Vs + d * TVPITCH + ((g ^ ((d >> 3) & 3)) * 16) + j * 2) = vr[e];
+    }
+  }
+  // S^T = K Q^T straight from global (frame r, 16-byte pieces); rows >= F are zero
+  f32x16 st;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    half8_t kf = zero8, qf = zero8;
+    if (r < F) {
+      kf = *reinterpret_cast<const half8_t*>(kb + (long)r * p.k_ts + 16 * s + 8 * h);
+      qf = *reinterpret_cast<const half8_t*>(qb + (long)r * p.q_ts + 16 * s + 8 * h);
+    }
+    st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, st, 0, 0, 0);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int key = 8 * (e >> 2) + 4 * h + (e & 3);
+    const float sv = key < F ? st[e] * p.scale_log2 : -INFINITY;
+    st[e] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float ps = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float pv = exp2f(st[e] - mx);
+    st[e] = pv;
+    ps += pv;
+  }
+  ps += __shfl_xor(ps, 32);
+  const float inv = 1.0f / ps;
+
+  __syncthreads();  // V^T image written (wave-private, but orders the ds_write/ds_read for the compiler too)
+  f32x16 ot[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    half8_t pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (half_t)st[8 * s + j];
+    const int g = s * 2 + h;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int d = 32 * dt + r;
+      const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + d * TVPITCH + ((g ^ ((d >> 3) & 3)) * 16));
+      ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
+    }
+  }
+  if (active && r < F) {
+    half_t* op = p.out + smp * p.o_bs + px * p.o_ps + (long)r * p.o_ts + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][q * 4 + e] * inv);
+        *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h) = o;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
+  MVOC_REQUIRE(d && d->q && d->k && d->v && d->out, -1, "flash_attn: null operand");
+  MVOC_REQUIRE(d->nbatch > 0 && d->heads > 0 && d->tq > 0 && d->tk > 0, -1, "flash_attn: empty problem");
+  MVOC_REQUIRE(d->nbatch <= 65535 && d->heads <= 65535, -2, "flash_attn: grid too large");
+  MVOC_REQUIRE(d->q_ts % 8 == 0 && d->k_ts % 8 == 0 && d->v_ts % 8 == 0 && d->o_ts % 4 == 0, -2,
+               "flash_attn: row strides must keep 16-byte alignment");
+  AttnArgs a;
+  a.q = (const half_t*)d->q; a.k = (const half_t*)d->k; a.v = (const half_t*)d->v; a.out = (half_t*)d->out;
+  a.q_bs = d->q_bs; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_ts = d->k_ts; a.v_bs = d->v_bs; a.v_ts = d->v_ts;
+  a.o_bs = d->o_bs; a.o_ts = d->o_ts;
+  a.nbatch = d->nbatch; a.heads = d->heads; a.tq = d->tq; a.tk = d->tk; a.kv_bdiv = d->kv_bdiv > 0 ? d->kv_bdiv : 1;
+  a.scale_log2 = 0.125f * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_FLASH, s, 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * 64);
+  dim3 grid((d->tq + 127) / 128, d->heads, d->nbatch);
+  hipLaunchKernelGGL(flash_kernel, grid, dim3(256), 0, s, a);
+  return mvoc_check_launch("flash_kernel");
+}
+
+extern "C" int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream) {
+  MVOC_REQUIRE(d && d->q && d->k && d->v && d->out, -1, "temporal_attn: null operand");
+  MVOC_REQUIRE(d->nsample > 0 && d->hw > 0 && d->heads > 0, -1, "temporal_attn: empty problem");
+  MVOC_REQUIRE(d->frames >= 1 && d->frames <= 32, -2, "temporal_attn: frames (%d) must be in [1, 32]", d->frames);
+  MVOC_REQUIRE(d->q_ts % 8 == 0 && d->k_ts % 8 == 0 && d->v_ts % 8 == 0 && d->o_ts % 4 == 0 && d->q_ps % 8 == 0 &&
+                   d->k_ps % 8 == 0 && d->v_ps % 8 == 0 && d->o_ps % 4 == 0,
+               -2, "temporal_attn: strides must keep 16-byte alignment");
+  TAttnArgs a;
+  a.q = (const half_t*)d->q; a.k = (const half_t*)d->k; a.v = (const half_t*)d->v; a.out = (half_t*)d->out;
+  a.q_bs = d->q_bs; a.q_ps = d->q_ps; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_ps = d->k_ps; a.k_ts = d->k_ts;
+  a.v_bs = d->v_bs; a.v_ps = d->v_ps; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_ps = d->o_ps; a.o_ts = d->o_ts;
+  a.nsample = d->nsample; a.hw = d->hw; a.heads = d->heads; a.frames = d->frames;
+  a.ntask = (long)d->nsample * d->hw * d->heads;
+  a.scale_log2 = 0.125f * 1.4426950408889634f;
+  const long nblk = (a.ntask + 3) / 4;
+  MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "temporal_attn: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes: q, k, v read + out written once
+  MvocProfScope prof(MVOC_FAM_TATTN, s, 4.0 * a.ntask * d->frames * 64 * 2);
+  hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
+  return mvoc_check_launch("tattn_kernel");
+}

@@ -1,0 +1,349 @@
+// Implicit-GEMM on MFMA for gfx950: every linear / 3x3 conv / 1x1 conv / (3,1,1) temporal conv of the
+// I2VGen-XL UNet runs through this one kernel family.
+//
+//   out[m, n] = epilogue( sum_k A(m, k) * W[n, k] )       fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16)
+//
+// * A(m, k) is gathered on the fly from channels-last activations:
+//     PLAIN      A(m,k) = a[m*lda + k]                                         (linear, 1x1 conv)
+//     CONV3X3    k = tap*cin + c, tap = 3*ky+kx: pixel (oy*stride+ky-1, ox*stride+kx-1), zero outside;
+//                optional nearest-upsample of the source folded into the index (Upsample2D + conv)
+//     TEMPORAL3  k = tap*cin + c: same pixel of frame f+tap-1, zero outside [0, frames)
+//   In all modes channels c < c1 come from `a`, the rest from `a2` (torch.cat([x, skip], dim=1) never
+//   materialised).
+// * MFMA orientation is "weights as the row operand": D[row = out-channel n][col = pixel m].  In the
+//   32x32 accumulator layout (col = lane&31, row = 8*(reg>>2) + 4*(lane>>5) + (reg&3)) every lane then owns 4
+//   CONSECUTIVE output channels of one pixel per register quad -> 8-byte vector stores / bias / residual loads
+//   with no LDS transpose, and GEGLU's (value, gate) pairs sit in the same lane.
+// * Block = WN x WM waves, each wave TN x TM tiles of 32x32; K step 32 (2 MFMA k-steps); global -> register ->
+//   LDS staging, double-buffered, one barrier per K step; LDS rows padded to 80 B so the ds_read_b128 fragment
+//   reads are bank-conflict free (stride 20 dwords: 5r mod 16 is a bijection over a 16-lane group).
+// * 1-D grid with an XCD-aware remap: the n-tiles of one m-tile are neighbours on one XCD, so the activation
+//   tile they share is served by that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int ROWB = 80;  // LDS row pitch in bytes (64 B of data + 16 B pad)
+
+struct GemmArgs {
+  const half_t* a;
+  const half_t* a2;
+  const half_t* w;
+  half_t* out;
+  const half_t* bias;
+  const half_t* rowadd;
+  const half_t* resid;
+  int M, N, K, n_store;
+  int ldo, ldr, ld_rowadd, rowadd_div;
+  int a_mode, lda, lda2, c1, cin;
+  int nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
+  float ups_sh, ups_sw;
+  int frames, hw;
+  int act;
+  int n_tiles, m_tiles;
+};
+
+struct RowInfo {   // per staged activation row (fixed for the whole K loop)
+  int m;           // global row, -1 if beyond M
+  int y0, x0;      // conv: oy*stride-1, ox*stride-1
+  int img;         // conv: image index; temporal: frame index
+};
+
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(const GemmArgs p) {
+  constexpr int NT = WN * WM * 64;
+  constexpr int BN = WN * TN * 32;
+  constexpr int BM = WM * TM * 32;
+  constexpr int CHW = (BN * 4 + NT - 1) / NT;  // 16-byte chunks of W per thread per K step
+  constexpr int CHA = (BM * 4 + NT - 1) / NT;
+  constexpr int STAGE = (BN + BM) * ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave / WM, wm = wave % WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (int)(logical % (unsigned)p.n_tiles) * BN;
+  const int m0 = (int)(logical / (unsigned)p.n_tiles) * BM;
+
+  const int kc = tid & 3;  // NT is a multiple of 4: every chunk of this thread has the same k sub-offset
+  // ---- per-thread staging bookkeeping ---------------------------------------------------------
+  RowInfo ri[CHA];
+#pragma unroll
+  for (int i = 0; i < CHA; ++i) {
+    const int row = (tid + i * NT) >> 2;
+    const int m = m0 + row;
+    ri[i].m = (row < BM && m < p.M) ? m : -1;
+    ri[i].y0 = ri[i].x0 = ri[i].img = 0;
+    if (ri[i].m >= 0) {
+      if (p.a_mode == MVOC_A_CONV3X3) {
+        const int hwout = p.hout * p.wout;
+        const int img = m / hwout;
+        const int rem = m - img * hwout;
+        const int oy = rem / p.wout;
+        ri[i].img = img;
+        ri[i].y0 = oy * p.stride - 1;
+        ri[i].x0 = (rem - oy * p.wout) * p.stride - 1;
+      } else if (p.a_mode == MVOC_A_TEMPORAL3) {
+        ri[i].img = (m / p.hw) % p.frames;
+      }
+    }
+  }
+  // running (tap, channel) of this thread's k position kk = k0 + kc*8
+  int tap = 0, ch = kc * 8;
+  while (ch >= p.cin) { ch -= p.cin; ++tap; }
+
+  half8_t regW[CHW], regA[CHA];
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < CHW; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 2;
+      regW[i] = zero8;
+      if (row < BN && n0 + row < p.N)
+        regW[i] = *reinterpret_cast<const half8_t*>(p.w + (size_t)(n0 + row) * p.K + k0 + kc * 8);
+    }
+    const half_t* src = p.a;
+    int ld = p.lda, cc = ch;
+    if (ch >= p.c1) { src = p.a2; ld = p.lda2; cc = ch - p.c1; }
+    int ky = 0, kx = 0;
+    if (p.a_mode == MVOC_A_CONV3X3) { ky = tap / 3; kx = tap - ky * 3; }
+#pragma unroll
+    for (int i = 0; i < CHA; ++i) {
+      regA[i] = zero8;
+      const int m = ri[i].m;
+      if (m < 0) continue;
+      long srow;
+      if (p.a_mode == MVOC_A_PLAIN) {
+        srow = m;
+      } else if (p.a_mode == MVOC_A_TEMPORAL3) {
+        const int f2 = ri[i].img + tap - 1;
+        if (f2 < 0 || f2 >= p.frames || tap > 2) continue;
+        srow = (long)m + (long)(tap - 1) * p.hw;
+      } else {
+        if (tap > 8) continue;
+        int iy = ri[i].y0 + ky, ix = ri[i].x0 + kx;
+        if (iy < 0 || ix < 0 || iy >= p.hup || ix >= p.wup) continue;
+        if (p.upsample) {
+          iy = min((int)floorf(iy * p.ups_sh), p.hsrc - 1);
+          ix = min((int)floorf(ix * p.ups_sw), p.wsrc - 1);
+        }
+        srow = ((long)ri[i].img * p.hsrc + iy) * p.wsrc + ix;
+      }
+      regA[i] = *reinterpret_cast<const half8_t*>(src + srow * ld + cc);
+    }
+    ch += BK;
+    while (ch >= p.cin) { ch -= p.cin; ++tap; }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < CHW; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 2;
+      if (row < BN) *reinterpret_cast<half8_t*>(base + row * ROWB + kc * 16) = regW[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CHA; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 2;
+      if (row < BM) *reinterpret_cast<half8_t*>(base + BN * ROWB + row * ROWB + kc * 16) = regA[i];
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROWB + h * 16;
+    const char* al = smem + cur * STAGE + BN * ROWB + (wm * TM * 32 + r) * ROWB + h * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8_t wf[TN], af[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel m = tile_m + r and, per register quad q, channels n..n+3 ---------------
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + (wm * TM + j) * 32 + r;
+    if (m >= p.M) continue;
+    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd : nullptr;
+    const half_t* rs = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
+    half_t* orow = p.out + (size_t)m * p.ldo;
+    if (p.act == MVOC_ACT_GEGLU) {
+      if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; i += 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nh = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;  // packed row of the value half
+            if (nh >= p.N) continue;
+            const int no = (n0 + (wn * TN + i) * 32) / 2 + 8 * q + 4 * h;
+            half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+            if (p.bias) {
+              bh = *reinterpret_cast<const half4_t*>(p.bias + nh);
+              bg = *reinterpret_cast<const half4_t*>(p.bias + nh + 32);
+            }
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float hv = r16(acc[i][j][q * 4 + e] + (float)bh[e]);
+              const float gv = r16(acc[i + 1][j][q * 4 + e] + (float)bg[e]);
+              float v = r16(hv * r16(gelu_erf_f(gv)));
+              if (rs) v = r16(v + (float)rs[no + e]);
+              o[e] = (half_t)v;
+            }
+            *reinterpret_cast<half4_t*>(orow + no) = o;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+          if (n >= p.n_store) continue;
+          half4_t b4 = {0, 0, 0, 0};
+          if (p.bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
+          if (ra) {
+            const half4_t t4 = *reinterpret_cast<const half4_t*>(ra + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
+          }
+          if (p.act == MVOC_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+          } else if (p.act == MVOC_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(gelu_erf_f(v[e]));
+          }
+          if (rs) {
+            const half4_t r4 = *reinterpret_cast<const half4_t*>(rs + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)r4[e]);
+          }
+          if (n + 4 <= p.n_store) {
+            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(orow + n) = o;
+          } else {
+            for (int e = 0; e < 4 && n + e < p.n_store; ++e) orow[n + e] = (half_t)v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WN, int WM, int TN, int TM>
+int launch(const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+  a.n_tiles = (a.N + BN - 1) / BN;
+  a.m_tiles = (a.M + BM - 1) / BM;
+  const long nblk = (long)a.n_tiles * a.m_tiles;
+  if (nblk <= 0 || nblk > 0x7fffffffL) {
+    mvoc_set_error("gemm: grid of %ld blocks", nblk);
+    return -2;
+  }
+  hipLaunchKernelGGL((gemm_kernel<WN, WM, TN, TM>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
+  return mvoc_check_launch("gemm_kernel");
+}
+
+}  // namespace
+
+extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
+  MVOC_REQUIRE(d && d->a && d->w && d->out, -1, "gemm: null operand");
+  MVOC_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, -1, "gemm: empty problem m=%ld n=%ld k=%ld", (long)d->m, (long)d->n,
+               (long)d->k);
+  MVOC_REQUIRE(d->m < (1LL << 31) && d->n < (1 << 24) && d->k < (1 << 24), -2, "gemm: problem too large");
+  MVOC_REQUIRE(d->n % 32 == 0 && d->k % BK == 0, -2, "gemm: n (%ld) must be a multiple of 32 and k (%ld) of %d",
+               (long)d->n, (long)d->k, BK);
+  MVOC_REQUIRE(d->cin > 0 && d->cin % 8 == 0 && d->c1 % 8 == 0 && d->c1 <= d->cin, -2,
+               "gemm: cin (%d) and c1 (%d) must be multiples of 8", d->cin, d->c1);
+  MVOC_REQUIRE(d->a2 || d->c1 == d->cin, -1, "gemm: c1 < cin needs a second source");
+  MVOC_REQUIRE(d->a_mode >= 0 && d->a_mode <= 2, -1, "gemm: bad a_mode %d", d->a_mode);
+  MVOC_REQUIRE(d->ldo % 4 == 0 && (d->resid == nullptr || d->ldr % 4 == 0), -2, "gemm: ldo/ldr must be multiples of 4");
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = (const half_t*)d->a; a.a2 = (const half_t*)d->a2; a.w = (const half_t*)d->w; a.out = (half_t*)d->out;
+  a.bias = (const half_t*)d->bias; a.rowadd = (const half_t*)d->rowadd; a.resid = (const half_t*)d->resid;
+  a.M = (int)d->m; a.N = (int)d->n; a.K = (int)d->k;
+  a.n_store = d->n_store > 0 ? d->n_store : (int)d->n;
+  a.ldo = d->ldo; a.ldr = d->ldr; a.ld_rowadd = d->ld_rowadd; a.rowadd_div = d->rowadd_div > 0 ? d->rowadd_div : 1;
+  a.a_mode = d->a_mode; a.lda = d->lda; a.lda2 = d->lda2; a.c1 = d->c1; a.cin = d->cin;
+  a.nimg = d->nimg; a.hout = d->hout; a.wout = d->wout; a.hsrc = d->hsrc; a.wsrc = d->wsrc;
+  a.stride = d->stride > 0 ? d->stride : 1; a.upsample = d->upsample;
+  a.hup = d->upsample ? d->hup : d->hsrc; a.wup = d->upsample ? d->wup : d->wsrc;
+  a.ups_sh = d->upsample ? (float)d->hsrc / (float)d->hup : 1.f;
+  a.ups_sw = d->upsample ? (float)d->wsrc / (float)d->wup : 1.f;
+  a.frames = d->frames; a.hw = d->hw; a.act = d->act;
+  if (d->a_mode == MVOC_A_CONV3X3) {
+    MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
+    MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");
+    MVOC_REQUIRE(d->k >= 9 * (int64_t)d->cin, -1, "gemm: conv k < 9*cin");
+  } else if (d->a_mode == MVOC_A_TEMPORAL3) {
+    MVOC_REQUIRE(d->frames > 0 && d->hw > 0 && d->m % ((int64_t)d->frames * d->hw) == 0, -1, "gemm: temporal dims");
+    MVOC_REQUIRE(d->k == 3 * (int64_t)d->cin, -1, "gemm: temporal k != 3*cin");
+  } else {
+    MVOC_REQUIRE(d->k == d->cin, -1, "gemm: plain mode needs cin == k");
+  }
+  if (d->act == MVOC_ACT_GEGLU) {
+    MVOC_REQUIRE(d->n % 64 == 0, -2, "gemm: GEGLU needs n %% 64 == 0");
+    a.n_store = (int)d->n / 2;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)d->m * (double)d->n * (double)d->k;
+  MvocProfScope prof(MVOC_FAM_GEMM, s, flops);
+  int tile = d->tile;
+  if (tile == 0) {
+    if (d->act == MVOC_ACT_GEGLU) tile = 1;
+    else if (d->n % 160 == 0 && d->m >= 2048) tile = 2;
+    else if (d->n % 128 == 0 && d->m >= 2048) tile = 1;
+    else tile = 3;
+  }
+  switch (tile) {
+    case 1: return launch<2, 2, 2, 2>(a, s);  // 128 x 128
+    case 2:
+      MVOC_REQUIRE(d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 2 cannot do GEGLU");
+      return launch<1, 4, 5, 1>(a, s);        // 160 x 128
+    case 3:
+      if (d->act == MVOC_ACT_GEGLU) return launch<1, 4, 2, 1>(a, s);
+      return launch<2, 2, 1, 2>(a, s);        // 64 x 128
+    case 4: return launch<1, 4, 2, 1>(a, s);  // 64 x 128, waves along m
+    default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
+  }
+}

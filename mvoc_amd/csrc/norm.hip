@@ -1,0 +1,250 @@
+// GroupNorm(+SiLU) and LayerNorm on channels-last rows (HBM-bound; 16-byte loads along C, deterministic).
+//
+// GroupNorm: a "sample" is rows_per_sample consecutive rows (one image = H*W rows for the 4-D norms, one video =
+// F*H*W rows for the 5-D norms inside TemporalConvLayer / TransformerTemporalModel).  Three launches:
+//   gn_partial : grid (nchunk, nsample) -- each block reduces a slab of rows to per-group (count, mean, M2)
+//   gn_final   : grid (nsample)         -- Chan-combines the slabs in fixed order -> (mean, rstd) per group
+//   gn_apply   : grid (nchunk, nsample) -- y = silu?( (x-mean)*rstd*gamma + beta ), fp16-rounded like the
+//                                          reference's group_norm -> silu op pair
+// The input may be a channel concat of two tensors (decoder skip connections): the concat is only ever
+// materialised as the *normalised* output.
+#include "common.h"
+
+namespace {
+
+struct GnArgs {
+  const half_t* x;
+  const half_t* x2;
+  const half_t* gamma;
+  const half_t* beta;
+  half_t* out;
+  float* ws;  // [nsample][nchunk][G][3] partials, then [nsample][G][2] finals
+  int nsample, R, c, c1, c2, G, cpg, silu;
+  int nchunk, rows_per_chunk;
+  int CW, RY, npass;
+  float eps;
+};
+
+__device__ __forceinline__ const half_t* gn_src(const GnArgs& p, long row, int ch) {
+  return ch < p.c1 ? p.x + row * p.c1 + ch : p.x2 + row * p.c2 + (ch - p.c1);
+}
+
+__global__ __launch_bounds__(256) void gn_partial(const GnArgs p) {
+  __shared__ float lsum[2560], lsq[2560];
+  const int tid = threadIdx.x;
+  const int cx = tid % p.CW, ry = tid / p.CW;
+  const int smp = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * p.rows_per_chunk;
+  const int r1 = min(r0 + p.rows_per_chunk, p.R);
+  const long rowbase = (long)smp * p.R;
+  for (int pass = 0; pass < p.npass; ++pass) {
+    const int cc = pass * p.CW + cx;
+    const bool on = ry < p.RY && cc * 8 < p.c;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (on) {
+      for (int rr = r0 + ry; rr < r1; rr += p.RY) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr, cc * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        lsum[ry * p.CW * 8 * p.npass + cc * 8 + e] = s[e];
+        lsq[ry * p.CW * 8 * p.npass + cc * 8 + e] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < p.G) {
+    float s = 0.f, q = 0.f;
+    const int stride = p.CW * 8 * p.npass;
+    for (int y = 0; y < p.RY; ++y)
+      for (int ch = tid * p.cpg; ch < (tid + 1) * p.cpg; ++ch) {
+        s += lsum[y * stride + ch];
+        q += lsq[y * stride + ch];
+      }
+    const float n = (float)(r1 - r0) * p.cpg;
+    const float mean = n > 0 ? s / n : 0.f;
+    float* o = p.ws + (((long)smp * p.nchunk + chunk) * p.G + tid) * 3;
+    o[0] = n;
+    o[1] = mean;
+    o[2] = fmaxf(q - s * mean, 0.f);
+  }
+}
+
+__global__ void gn_final(const GnArgs p) {
+  const int g = threadIdx.x, smp = blockIdx.x;
+  if (g >= p.G) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = 0; c < p.nchunk; ++c) {
+    const float* in = p.ws + (((long)smp * p.nchunk + c) * p.G + g) * 3;
+    const float nb = in[0], mb = in[1], m2b = in[2];
+    if (nb <= 0.f) continue;
+    const float nt = n + nb, delta = mb - mean;
+    mean += delta * (nb / nt);
+    m2 += m2b + delta * delta * (n * nb / nt);
+    n = nt;
+  }
+  float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + ((long)smp * p.G + g) * 2;
+  fin[0] = mean;
+  fin[1] = rsqrtf(m2 / n + p.eps);
+}
+
+__global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
+  const int tid = threadIdx.x;
+  const int cx = tid % p.CW, ry = tid / p.CW;
+  const int smp = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * p.rows_per_chunk;
+  const int r1 = min(r0 + p.rows_per_chunk, p.R);
+  const long rowbase = (long)smp * p.R;
+  const float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + (long)smp * p.G * 2;
+  if (ry >= p.RY) return;
+  for (int pass = 0; pass < p.npass; ++pass) {
+    const int cc = pass * p.CW + cx;
+    if (cc * 8 >= p.c) continue;
+    float sc[8], sh[8];
+    const half8_t gm = *reinterpret_cast<const half8_t*>(p.gamma + cc * 8);
+    const half8_t bt = *reinterpret_cast<const half8_t*>(p.beta + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (cc * 8 + e) / p.cpg;
+      const float mean = fin[g * 2], rstd = fin[g * 2 + 1];
+      sc[e] = rstd * (float)gm[e];
+      sh[e] = (float)bt[e] - mean * sc[e];
+    }
+    for (int rr = r0 + ry; rr < r1; rr += p.RY) {
+      const half8_t v = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr, cc * 8));
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = r16((float)v[e] * sc[e] + sh[e]);
+        if (p.silu) y = silu_f(y);
+        o[e] = (half_t)y;
+      }
+      *reinterpret_cast<half8_t*>(p.out + (rowbase + rr) * p.c + cc * 8) = o;
+    }
+  }
+}
+
+void gn_geometry(GnArgs& a) {
+  const int cchunks = a.c / 8;
+  a.CW = cchunks < 256 ? cchunks : 256;
+  a.RY = 256 / a.CW;
+  a.npass = (cchunks + a.CW - 1) / a.CW;
+  int want = 4096 / (a.nsample > 0 ? a.nsample : 1);
+  if (want < 1) want = 1;
+  int maxchunk = (a.R + a.RY * 4 - 1) / (a.RY * 4);  // at least 4 rows per thread-row
+  if (maxchunk < 1) maxchunk = 1;
+  a.nchunk = want < maxchunk ? want : maxchunk;
+  a.rows_per_chunk = (a.R + a.nchunk - 1) / a.nchunk;
+  a.nchunk = (a.R + a.rows_per_chunk - 1) / a.rows_per_chunk;
+}
+
+// ---- LayerNorm ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
+                                                 const half_t* __restrict__ beta, half_t* __restrict__ out, long rows,
+                                                 int c, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nch = c / 8;
+  const half_t* xr = x + row * c;
+  half8_t v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < nch) {
+      v[i] = *reinterpret_cast<const half8_t*>(xr + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / c + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < nch) {
+      const half8_t gm = *reinterpret_cast<const half8_t*>(gamma + cc * 8);
+      const half8_t bt = *reinterpret_cast<const half8_t*>(beta + cc * 8);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+      *reinterpret_cast<half8_t*>(out + row * c + cc * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups) {
+  GnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nsample = nsample; a.R = rows_per_sample; a.c = c; a.G = groups;
+  if (nsample <= 0 || rows_per_sample <= 0 || c < 8 || groups <= 0) return 0;
+  gn_geometry(a);
+  return ((size_t)nsample * a.nchunk * groups * 3 + (size_t)nsample * groups * 2) * sizeof(float);
+}
+
+extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
+  MVOC_REQUIRE(d && d->x && d->gamma && d->beta && d->out && d->workspace, -1, "groupnorm: null operand");
+  MVOC_REQUIRE(d->nsample > 0 && d->rows_per_sample > 0, -1, "groupnorm: empty problem");
+  MVOC_REQUIRE(d->c % 8 == 0 && d->c1 % 8 == 0 && d->c <= 2560 && d->groups > 0 && d->groups <= 256 &&
+                   d->c % d->groups == 0,
+               -2, "groupnorm: unsupported channels %d (c1 %d) / groups %d", d->c, d->c1, d->groups);
+  MVOC_REQUIRE(d->x2 || d->c1 == d->c, -1, "groupnorm: c1 < c needs a second source");
+  MVOC_REQUIRE(d->nsample <= 65535, -2, "groupnorm: too many samples");
+  GnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const half_t*)d->x; a.x2 = (const half_t*)d->x2; a.gamma = (const half_t*)d->gamma;
+  a.beta = (const half_t*)d->beta; a.out = (half_t*)d->out; a.ws = (float*)d->workspace;
+  a.nsample = d->nsample; a.R = d->rows_per_sample; a.c = d->c; a.c1 = d->c1; a.c2 = d->c - d->c1;
+  a.G = d->groups; a.cpg = d->c / d->groups; a.silu = d->silu; a.eps = d->eps;
+  gn_geometry(a);
+  const size_t need = mvoc_groupnorm_workspace_bytes(d->nsample, d->rows_per_sample, d->c, d->groups);
+  MVOC_REQUIRE(d->workspace_bytes >= need, -1, "groupnorm: workspace %zu < %zu bytes", d->workspace_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes: read x once for stats + once for apply is the implementation; compulsory = read + write
+  MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
+  dim3 grid(a.nchunk, a.nsample);
+  hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
+  return mvoc_check_launch("groupnorm");
+}
+
+extern "C" int mvoc_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int64_t rows, int32_t c,
+                                  float eps, void* stream) {
+  MVOC_REQUIRE(x && gamma && beta && out, -1, "layernorm: null operand");
+  MVOC_REQUIRE(rows > 0 && c >= 8 && c % 8 == 0 && c <= 2048, -2, "layernorm: unsupported c %d", c);
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_LN, s, 2.0 * 2.0 * (double)rows * c);
+  const long nblk = (rows + 3) / 4;
+  MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "layernorm: too many rows");
+  hipLaunchKernelGGL(ln_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const half_t*)x, (const half_t*)gamma,
+                     (const half_t*)beta, (half_t*)out, (long)rows, c, eps);
+  return mvoc_check_launch("ln_kernel");
+}

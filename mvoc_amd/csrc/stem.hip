@@ -1,0 +1,284 @@
+// Stem / small ops of the UNet (pipeline_i2vgen_xl.py:166-290, 351-357): a few MB of traffic per step,
+// latency-bound.  Simple one-thread-per-output kernels on channels-last data.
+#include "common.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int nb, int dim, half_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= nb * dim) return;
+  const int b = i / dim, j = i % dim;
+  const int k = j < half ? j : j - half;
+  const float freq = expf(-logf(10000.0f) * (float)k / (float)half);
+  const float ang = t[b] * freq;
+  out[i] = (half_t)(j < half ? cosf(ang) : sinf(ang));
+}
+
+__global__ void act_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, long n, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)x[i];
+  out[i] = (half_t)(act == MVOC_ACT_SILU ? silu_f(v) : act == MVOC_ACT_GELU ? gelu_erf_f(v) : v);
+}
+
+__global__ void add_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (half_t)((float)a[i] + (float)b[i]);
+}
+
+// x [nimg][h][w][cin] -> out [nimg][ho][wo][cout], 3x3, pad 1; thread = (pixel, cout)
+__global__ void conv3x3_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                     const half_t* __restrict__ bias, half_t* __restrict__ out, int nimg, int h, int wd,
+                                     int cin, int cout, int stride, int ho, int wo, int silu) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nimg * ho * wo * cout;
+  if (i >= total) return;
+  const int co = (int)(i % cout);
+  long pix = i / cout;
+  const int ox = (int)(pix % wo);
+  pix /= wo;
+  const int oy = (int)(pix % ho);
+  const int img = (int)(pix / ho);
+  float acc = 0.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * stride + ky - 1;
+    if (iy < 0 || iy >= h) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * stride + kx - 1;
+      if (ix < 0 || ix >= wd) continue;
+      const half_t* xp = x + (((long)img * h + iy) * wd + ix) * cin;
+      const half_t* wp = w + ((long)co * 9 + ky * 3 + kx) * cin;
+      for (int c = 0; c < cin; ++c) acc += (float)xp[c] * (float)wp[c];
+    }
+  }
+  float v = r16(acc + (bias ? (float)bias[co] : 0.f));
+  if (silu) v = silu_f(v);
+  out[i] = (half_t)v;
+}
+
+__global__ void avgpool_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int nimg, int h, int w, int c,
+                               int oh, int ow) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nimg * oh * ow * c;
+  if (i >= total) return;
+  const int ch = (int)(i % c);
+  long pix = i / c;
+  const int ox = (int)(pix % ow);
+  pix /= ow;
+  const int oy = (int)(pix % oh);
+  const int img = (int)(pix / oh);
+  const int y0 = (oy * h) / oh, y1 = ((oy + 1) * h + oh - 1) / oh;
+  const int x0 = (ox * w) / ow, x1 = ((ox + 1) * w + ow - 1) / ow;
+  float s = 0.f;
+  for (int y = y0; y < y1; ++y)
+    for (int xx = x0; xx < x1; ++xx) s += (float)x[(((long)img * h + y) * w + xx) * c + ch];
+  out[i] = (half_t)(s / (float)((y1 - y0) * (x1 - x0)));
+}
+
+__global__ void ncfhw_to_tokens_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int b, int c, int f, int hw,
+                                       int ldo, int coff) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)b * f * hw;
+  if (i >= total) return;
+  const int p = (int)(i % hw);
+  const long bf = i / hw;
+  const int fi = (int)(bf % f), bi = (int)(bf / f);
+  for (int ch = 0; ch < c; ++ch) out[i * ldo + coff + ch] = x[(((long)bi * c + ch) * f + fi) * hw + p];
+}
+
+__global__ void tokens_to_ncfhw_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int b, int c, int f, int hw,
+                                       int ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)b * c * f * hw;
+  if (i >= total) return;
+  const int p = (int)(i % hw);
+  long r = i / hw;
+  const int fi = (int)(r % f);
+  r /= f;
+  const int ch = (int)(r % c);
+  const int bi = (int)(r / c);
+  out[i] = x[(((long)bi * f + fi) * hw + p) * ld + ch];
+}
+
+// I2VGenXLTransformerTemporalEncoder, dim 4, 2 heads of 4, FF 4->16->4 (gelu).  thread = (sample, pixel, frame i)
+struct Enc4Params {
+  half_t ln_g[4], ln_b[4], wq[32], wk[32], wv[32], wo[32], bo[4], w1[64], b1[16], w2[64], b2[4];
+};
+
+__device__ __forceinline__ void enc4_ln(const half_t* xp, const Enc4Params& P, float* y) {
+  float v[4], mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { v[c] = (float)xp[c]; mean += v[c]; }
+  mean *= 0.25f;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) var += (v[c] - mean) * (v[c] - mean);
+  const float rstd = rsqrtf(var * 0.25f + 1e-5f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) y[c] = r16((v[c] - mean) * rstd * (float)P.ln_g[c] + (float)P.ln_b[c]);
+}
+
+__global__ void temporal_encoder4_kernel(const half_t* __restrict__ x, const Enc4Params* __restrict__ params,
+                                         half_t* __restrict__ out, int b, int f, int hw, int ldo, int coff) {
+  __shared__ Enc4Params P;
+  for (int i = threadIdx.x; i < (int)(sizeof(Enc4Params) / sizeof(half_t)); i += blockDim.x)
+    reinterpret_cast<half_t*>(&P)[i] = reinterpret_cast<const half_t*>(params)[i];
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)b * f * hw;
+  if (idx >= total) return;
+  const int p = (int)(idx % hw);
+  const long bf = idx / hw;
+  const int fi = (int)(bf % f), bi = (int)(bf / f);
+  const half_t* xi = x + idx * 4;
+  float yi[4], q[8];
+  enc4_ln(xi, P, yi);
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += yi[c] * (float)P.wq[o * 4 + c];
+    q[o] = r16(s);
+  }
+  // online softmax over the frames of this pixel, both heads
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < f; ++j) {
+    const half_t* xj = x + (((long)bi * f + j) * hw + p) * 4;
+    float yj[4], k[8], v[8];
+    enc4_ln(xj, P, yj);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float sk = 0.f, sv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sk += yj[c] * (float)P.wk[o * 4 + c];
+        sv += yj[c] * (float)P.wv[o * 4 + c];
+      }
+      k[o] = r16(sk);
+      v[o] = r16(sv);
+    }
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) s += q[hd * 4 + d] * k[hd * 4 + d];
+      s *= 0.5f;  // 1/sqrt(head_dim 4)
+      const float mn = fmaxf(m[hd], s);
+      const float a = __expf(m[hd] - mn), pj = __expf(s - mn);
+      l[hd] = l[hd] * a + pj;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) acc[hd * 4 + d] = acc[hd * 4 + d] * a + pj * v[hd * 4 + d];
+      m[hd] = mn;
+    }
+  }
+  float att[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) att[o] = r16(acc[o] / l[o >> 2]);
+  float h1[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) s += att[o] * (float)P.wo[c * 8 + o];
+    h1[c] = r16(r16(s + (float)P.bo[c]) + (float)xi[c]);
+  }
+  float ff[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += h1[c] * (float)P.w1[o * 4 + c];
+    ff[o] = r16(gelu_erf_f(r16(s + (float)P.b1[o])));
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) s += ff[o] * (float)P.w2[c * 16 + o];
+    out[idx * ldo + coff + c] = (half_t)(r16(s + (float)P.b2[c]) + h1[c]);
+  }
+}
+
+inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int mvoc_timestep_embedding_f16(const float* t_dev, int32_t nb, int32_t dim, void* out, void* stream) {
+  MVOC_REQUIRE(t_dev && out && nb > 0 && dim > 0 && dim % 2 == 0, -1, "timestep_embedding: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 2.0 * nb * dim);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(nblk((long)nb * dim)), dim3(256), 0, s, t_dev, nb, dim, (half_t*)out);
+  return mvoc_check_launch("timestep_embedding_kernel");
+}
+
+extern "C" int mvoc_act_f16(const void* x, void* out, int64_t n, int32_t act, void* stream) {
+  MVOC_REQUIRE(x && out && n > 0, -1, "act: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * n);
+  hipLaunchKernelGGL(act_kernel, dim3(nblk(n)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, (long)n, act);
+  return mvoc_check_launch("act_kernel");
+}
+
+extern "C" int mvoc_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  MVOC_REQUIRE(a && b && out && n > 0, -1, "add: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 6.0 * n);
+  hipLaunchKernelGGL(add_kernel, dim3(nblk(n)), dim3(256), 0, s, (const half_t*)a, (const half_t*)b, (half_t*)out, (long)n);
+  return mvoc_check_launch("add_kernel");
+}
+
+extern "C" int mvoc_conv3x3_small_f16(const void* x, const void* w, const void* bias, void* out, int32_t nimg, int32_t h,
+                                      int32_t wd, int32_t cin, int32_t cout, int32_t stride, int32_t silu, void* stream) {
+  MVOC_REQUIRE(x && w && out && nimg > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0 && (stride == 1 || stride == 2), -1,
+               "conv3x3_small: bad args");
+  const int ho = (h + 2 - 3) / stride + 1, wo = (wd + 2 - 3) / stride + 1;
+  const long total = (long)nimg * ho * wo * cout;
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 2.0 * ((double)nimg * h * wd * cin + total));
+  hipLaunchKernelGGL(conv3x3_small_kernel, dim3(nblk(total)), dim3(256), 0, s, (const half_t*)x, (const half_t*)w,
+                     (const half_t*)bias, (half_t*)out, nimg, h, wd, cin, cout, stride, ho, wo, silu);
+  return mvoc_check_launch("conv3x3_small_kernel");
+}
+
+extern "C" int mvoc_adaptive_avgpool_f16(const void* x, void* out, int32_t nimg, int32_t h, int32_t w, int32_t c,
+                                         int32_t oh, int32_t ow, void* stream) {
+  MVOC_REQUIRE(x && out && nimg > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, -1, "avgpool: bad args");
+  const long total = (long)nimg * oh * ow * c;
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 2.0 * ((double)nimg * h * w * c + total));
+  hipLaunchKernelGGL(avgpool_kernel, dim3(nblk(total)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, nimg, h, w, c, oh,
+                     ow);
+  return mvoc_check_launch("avgpool_kernel");
+}
+
+extern "C" int mvoc_ncfhw_to_tokens_f16(const void* x, void* out, int32_t b, int32_t c, int32_t f, int32_t hw, int32_t ldo,
+                                        int32_t coff, void* stream) {
+  MVOC_REQUIRE(x && out && b > 0 && c > 0 && f > 0 && hw > 0 && ldo >= coff + c, -1, "ncfhw_to_tokens: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * b * c * f * hw);
+  hipLaunchKernelGGL(ncfhw_to_tokens_kernel, dim3(nblk((long)b * f * hw)), dim3(256), 0, s, (const half_t*)x,
+                     (half_t*)out, b, c, f, hw, ldo, coff);
+  return mvoc_check_launch("ncfhw_to_tokens_kernel");
+}
+
+extern "C" int mvoc_tokens_to_ncfhw_f16(const void* x, void* out, int32_t b, int32_t c, int32_t f, int32_t hw, int32_t ld,
+                                        void* stream) {
+  MVOC_REQUIRE(x && out && b > 0 && c > 0 && f > 0 && hw > 0 && ld >= c, -1, "tokens_to_ncfhw: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * b * c * f * hw);
+  hipLaunchKernelGGL(tokens_to_ncfhw_kernel, dim3(nblk((long)b * c * f * hw)), dim3(256), 0, s, (const half_t*)x,
+                     (half_t*)out, b, c, f, hw, ld);
+  return mvoc_check_launch("tokens_to_ncfhw_kernel");
+}
+
+extern "C" int mvoc_temporal_encoder4_f16(const void* x, const void* params, void* out, int32_t b, int32_t f, int32_t hw,
+                                          int32_t ldo, int32_t coff, void* stream) {
+  MVOC_REQUIRE(x && params && out && b > 0 && f > 0 && hw > 0 && ldo >= coff + 4, -1, "temporal_encoder4: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 16.0 * b * f * hw);
+  hipLaunchKernelGGL(temporal_encoder4_kernel, dim3(nblk((long)b * f * hw)), dim3(256), 0, s, (const half_t*)x,
+                     (const Enc4Params*)params, (half_t*)out, b, f, hw, ldo, coff);
+  return mvoc_check_launch("temporal_encoder4_kernel");
+}

@@ -1,0 +1,327 @@
+"""Thin tensor-level wrappers over the C ABI (include/mvoc_hip.h).
+
+PyTorch supplies device memory and the current HIP stream; every computation is a libmvoc_hip kernel.
+All activations are fp16, channels-last 2-D ``[rows, C]`` tensors (rows = B*F*H*W).
+"""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+from ._ffi import (A_CONV3X3, A_PLAIN, A_TEMPORAL3, ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc, GnDesc,
+                   PnpDesc, TAttnDesc, check, lib)
+
+__all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "pnp_blend_tokens",
+           "pnp_blend_nchw", "ddim_step", "latent_fusion", "timestep_embedding", "act", "add", "conv3x3_small",
+           "adaptive_avgpool", "ncfhw_to_tokens", "tokens_to_ncfhw", "temporal_encoder4", "ACT_NONE", "ACT_GEGLU",
+           "ACT_SILU", "ACT_GELU"]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float16):
+    if t is None:
+        return None
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f"mvoc_amd.ops: `{name}` must be a device tensor (this package has no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"mvoc_amd.ops: `{name}` must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rowmajor(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"mvoc_amd.ops: `{name}` must be a 2-D row-major view, got {tuple(t.shape)} / {t.stride()}")
+    return t.stride(0)
+
+
+def _gemm(d: GemmDesc):
+    check(lib.mvoc_gemm_f16(C.byref(d), _stream()), "gemm")
+
+
+def _fill_common(d, x, x2, w, out, bias, rowadd, rowadd_div, resid, act, n_store, tile):
+    d.a, d.a2, d.w, d.out = _ptr(x), _ptr(x2), _ptr(w), _ptr(out)
+    d.bias, d.rowadd, d.resid = _ptr(bias), _ptr(rowadd), _ptr(resid)
+    d.n = w.shape[0]
+    d.k = w.shape[1]
+    d.n_store = n_store
+    d.ldo = out.stride(0)
+    d.ldr = resid.stride(0) if resid is not None else 0
+    d.ld_rowadd = rowadd.stride(0) if rowadd is not None else 0
+    d.rowadd_div = rowadd_div
+    d.lda = x.stride(0)
+    d.lda2 = x2.stride(0) if x2 is not None else 0
+    d.act = act
+    d.tile = tile
+
+
+def _out_cols(w, n_store, act):
+    if act == ACT_GEGLU:
+        return w.shape[0] // 2
+    return n_store if n_store else w.shape[0]
+
+
+def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0):
+    """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T)."""
+    _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
+    _rowmajor(x, "x")
+    m = x.shape[0]
+    k1 = x.shape[1]
+    k2 = x2.shape[1] if x2 is not None else 0
+    if k1 + k2 != w.shape[1]:
+        raise RuntimeError(f"linear: K mismatch {k1}+{k2} vs weight {tuple(w.shape)}")
+    cols = _out_cols(w, n_store, act)
+    if out is None:
+        out = torch.empty((m, cols), dtype=torch.float16, device=x.device)
+    d = GemmDesc()
+    _fill_common(d, x, x2, w, out, bias, rowadd, rowadd_div, resid, act, cols if act != ACT_GEGLU else 0, tile)
+    d.m = m
+    d.a_mode = A_PLAIN
+    d.c1 = k1
+    d.cin = k1 + k2
+    _gemm(d)
+    return out
+
+
+def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
+            n_store=0, out=None, tile=0):
+    """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
+    ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D)."""
+    _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
+    _rowmajor(x, "x")
+    c1 = x.shape[1]
+    cin = c1 + (x2.shape[1] if x2 is not None else 0)
+    hup, wup = (upsample_to if upsample_to is not None else (h, wd))
+    ho = (hup + 2 - 3) // stride + 1
+    wo = (wup + 2 - 3) // stride + 1
+    m = nimg * ho * wo
+    cols = _out_cols(w, n_store, ACT_NONE)
+    if out is None:
+        out = torch.empty((m, cols), dtype=torch.float16, device=x.device)
+    d = GemmDesc()
+    _fill_common(d, x, x2, w, out, bias, rowadd, rowadd_div, resid, ACT_NONE, cols, tile)
+    d.m = m
+    d.a_mode = A_CONV3X3
+    d.c1, d.cin = c1, cin
+    d.nimg, d.hout, d.wout, d.hsrc, d.wsrc, d.stride = nimg, ho, wo, h, wd, stride
+    d.upsample = 1 if upsample_to is not None else 0
+    d.hup, d.wup = hup, wup
+    _gemm(d)
+    return out, ho, wo
+
+
+def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0):
+    """Conv3d (3,1,1), pad (1,0,0), on x [nvid*frames*hw, C]; w [N, 3*C] tap-major."""
+    _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(resid, "resid")
+    _rowmajor(x, "x")
+    m = nvid * frames * hw
+    if out is None:
+        out = torch.empty((m, w.shape[0]), dtype=torch.float16, device=x.device)
+    d = GemmDesc()
+    _fill_common(d, x, None, w, out, bias, None, 1, resid, ACT_NONE, w.shape[0], tile)
+    d.m = m
+    d.a_mode = A_TEMPORAL3
+    d.c1 = d.cin = x.shape[1]
+    d.frames, d.hw = frames, hw
+    _gemm(d)
+    return out
+
+
+def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None):
+    """softmax(q k^T / 8) v, head_dim 64.  q [nbatch*tq, >=heads*64] / k, v [(nbatch/kv_bdiv)*tk, ..] row-major views."""
+    _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
+    if out is None:
+        out = torch.empty((nbatch * tq, heads * 64), dtype=torch.float16, device=q.device)
+    d = AttnDesc()
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.q_ts, d.k_ts, d.v_ts, d.o_ts = _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(out, "out")
+    d.q_bs, d.k_bs, d.v_bs, d.o_bs = tq * d.q_ts, tk * d.k_ts, tk * d.v_ts, tq * d.o_ts
+    d.nbatch, d.heads, d.tq, d.tk, d.kv_bdiv = nbatch, heads, tq, tk, kv_bdiv
+    check(lib.mvoc_flash_attn_f16(C.byref(d), _stream()), "flash_attn")
+    return out
+
+
+def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
+    """Attention over the frame axis of canonical [nsample, frames, hw, C] rows (q/k/v may be column slices)."""
+    _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
+    if out is None:
+        out = torch.empty((nsample * frames * hw, heads * 64), dtype=torch.float16, device=q.device)
+    d = TAttnDesc()
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", out)):
+        ld = _rowmajor(t, name)
+        setattr(d, name + "_ps", ld)
+        setattr(d, name + "_ts", hw * ld)
+        setattr(d, name + "_bs", frames * hw * ld)
+    d.nsample, d.hw, d.heads, d.frames = nsample, hw, heads, frames
+    check(lib.mvoc_temporal_attn_f16(C.byref(d), _stream()), "temporal_attn")
+    return out
+
+
+def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2=None, out=None):
+    """GroupNorm over ``rows_per_sample`` rows x (C/groups) channels per sample, optional fused SiLU; [x | x2] concat."""
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(x2, "x2")
+    c1 = x.shape[1]
+    c = c1 + (x2.shape[1] if x2 is not None else 0)
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise RuntimeError("groupnorm: inputs must be contiguous")
+    if out is None:
+        out = torch.empty((nsample * rows_per_sample, c), dtype=torch.float16, device=x.device)
+    wsb = lib.mvoc_groupnorm_workspace_bytes(nsample, rows_per_sample, c, groups)
+    ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    d = GnDesc()
+    d.x, d.x2, d.gamma, d.beta, d.out = x.data_ptr(), _ptr(x2), gamma.data_ptr(), beta.data_ptr(), out.data_ptr()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.nsample, d.rows_per_sample, d.c, d.c1, d.groups, d.silu, d.eps = nsample, rows_per_sample, c, c1, groups, int(silu), eps
+    check(lib.mvoc_groupnorm_f16(C.byref(d), _stream()), "groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    if not x.is_contiguous():
+        raise RuntimeError("layernorm: x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.mvoc_layernorm_f16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                 eps, _stream()), "layernorm")
+    return out
+
+
+def _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0):
+    _chk(x, "x"), _chk(x2, "x2"), _chk(masks, "masks")
+    if masks.dim() != 4 or not masks.is_contiguous() or masks.shape[1] != frames:
+        raise RuntimeError(f"pnp: masks must be contiguous [nobj, F, mh, mw] fp16, got {tuple(masks.shape)}")
+    d = PnpDesc()
+    d.x, d.x2, d.masks = x.data_ptr(), _ptr(x2), masks.data_ptr()
+    d.chunk_stride, d.f_stride, d.p_stride = chunk_stride, f_stride, p_stride
+    d.nobj, d.frames, d.height, d.width, d.channels = masks.shape[0], frames, height, width, channels
+    d.mask_h, d.mask_w, d.base_chunk0 = masks.shape[2], masks.shape[3], int(base_chunk0)
+    return d
+
+
+def pnp_blend_tokens(x, masks, *, frames, height, width, channels, chunk_stride, f_stride, p_stride, x2=None,
+                     base_chunk0=False):
+    """In-place masked blend + scatter on channel-contiguous data (see include/mvoc_hip.h)."""
+    d = _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0)
+    check(lib.mvoc_pnp_blend_scatter_tokens(C.byref(d), _stream()), "pnp_blend_scatter_tokens")
+    return x
+
+
+def pnp_blend_nchw(x, masks, *, frames, x2=None, base_chunk0=True):
+    """In-place on x [(nobj+3)*F, C, H, W] (reference feature-map layout)."""
+    if x.dim() != 4 or not x.is_contiguous():
+        raise RuntimeError("pnp_blend_nchw: x must be contiguous [N, C, H, W]")
+    d = _pnp_desc(x, x2, masks, 0, 0, 0, frames, x.shape[2], x.shape[3], x.shape[1], base_chunk0)
+    check(lib.mvoc_pnp_blend_scatter_nchw(C.byref(d), _stream()), "pnp_blend_scatter_nchw")
+    return x
+
+
+def ddim_step(x, v_cond, coef_dev, v_uncond=None, out=None):
+    """coef_dev: fp32 device tensor {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev), guidance_scale}."""
+    _chk(x, "x"), _chk(v_cond, "v_cond"), _chk(v_uncond, "v_uncond"), _chk(coef_dev, "coef", torch.float32)
+    if out is None:
+        out = torch.empty_like(x)
+    for t in (x, v_cond, v_uncond, out):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("ddim_step: tensors must be contiguous")
+    check(lib.mvoc_ddim_step_f16(x.data_ptr(), _ptr(v_uncond), v_cond.data_ptr(), coef_dev.data_ptr(), out.data_ptr(),
+                                 x.numel(), _stream()), "ddim_step")
+    return out
+
+
+def latent_fusion(latents, bg, objs, masks, mix_ratio, obj_random_noise_fusion=False, out=None):
+    """objs / masks: contiguous [nobj, *latents.shape] fp16."""
+    _chk(latents, "latents"), _chk(bg, "bg"), _chk(objs, "objs"), _chk(masks, "masks")
+    if out is None:
+        out = torch.empty_like(latents)
+    n = latents.numel()
+    if objs.numel() != masks.numel() or objs.numel() % n:
+        raise RuntimeError("latent_fusion: objs/masks must be [nobj, ...latents.shape]")
+    check(lib.mvoc_latent_fusion_f16(latents.data_ptr(), bg.data_ptr(), objs.data_ptr(), masks.data_ptr(), out.data_ptr(),
+                                     objs.numel() // n, n, float(mix_ratio), int(obj_random_noise_fusion), _stream()),
+          "latent_fusion")
+    return out
+
+
+def timestep_embedding(t_dev, dim):
+    _chk(t_dev, "t", torch.float32)
+    out = torch.empty((t_dev.numel(), dim), dtype=torch.float16, device=t_dev.device)
+    check(lib.mvoc_timestep_embedding_f16(t_dev.data_ptr(), t_dev.numel(), dim, out.data_ptr(), _stream()), "timestep_embedding")
+    return out
+
+
+def act(x, kind):
+    _chk(x, "x")
+    out = torch.empty_like(x)
+    check(lib.mvoc_act_f16(x.data_ptr(), out.data_ptr(), x.numel(), kind, _stream()), "act")
+    return out
+
+
+def add(a, b):
+    _chk(a, "a"), _chk(b, "b")
+    out = torch.empty_like(a)
+    check(lib.mvoc_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
+    return out
+
+
+def conv3x3_small(x, w, bias, *, nimg, h, wd, cin, cout, stride=1, silu=False):
+    _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias")
+    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    out = torch.empty((nimg * ho * wo, cout), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_conv3x3_small_f16(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), nimg, h, wd, cin, cout, stride,
+                                     int(silu), _stream()), "conv3x3_small")
+    return out, ho, wo
+
+
+def adaptive_avgpool(x, *, nimg, h, w, c, oh, ow):
+    _chk(x, "x")
+    out = torch.empty((nimg * oh * ow, c), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_adaptive_avgpool_f16(x.data_ptr(), out.data_ptr(), nimg, h, w, c, oh, ow, _stream()), "adaptive_avgpool")
+    return out
+
+
+def ncfhw_to_tokens(x, out, coff=0):
+    """x [B,C,F,h,w] -> out [B*F*h*w, ld] channels coff..coff+C"""
+    _chk(x, "x"), _chk(out, "out")
+    b, c, f, h, w = x.shape
+    check(lib.mvoc_ncfhw_to_tokens_f16(x.contiguous().data_ptr(), out.data_ptr(), b, c, f, h * w, out.stride(0), coff,
+                                       _stream()), "ncfhw_to_tokens")
+    return out
+
+
+def tokens_to_ncfhw(x, b, c, f, h, w):
+    _chk(x, "x")
+    out = torch.empty((b, c, f, h, w), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_tokens_to_ncfhw_f16(x.data_ptr(), out.data_ptr(), b, c, f, h * w, x.stride(0), _stream()), "tokens_to_ncfhw")
+    return out
+
+
+def temporal_encoder4(x, params, out, *, b, f, hw, coff):
+    _chk(x, "x"), _chk(params, "params"), _chk(out, "out")
+    check(lib.mvoc_temporal_encoder4_f16(x.data_ptr(), params.data_ptr(), out.data_ptr(), b, f, hw, out.stride(0), coff,
+                                         _stream()), "temporal_encoder4")
+    return out
+
+
+def prof_enable(on):
+    lib.mvoc_prof_enable(int(on))
+
+
+def prof_reset():
+    lib.mvoc_prof_reset()
+
+
+def prof_collect():
+    n = len(_ffi.FAMILIES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    work = (C.c_double * n)()
+    check(lib.mvoc_prof_collect(ms, cnt, work), "prof_collect")
+    return {fam: {"ms": ms[i], "launches": cnt[i], "work": work[i]} for i, fam in enumerate(_ffi.FAMILIES)}

@@ -1,0 +1,613 @@
+"""I2VGen-XL 3D UNet on MI355X: the product forward of MVOC's denoising hot path.
+
+Mirrors the module tree of diffusers' ``I2VGenXLUNet`` (attribute paths, state_dict keys) so that the
+reference's hook protocol keeps working -- ``unet.up_blocks[i].attentions[j].transformer_blocks[0].attn1.processor``
+carries ``t`` / ``mask`` / ``injection_schedule`` / ``inject_background`` exactly as ``pnp_utils.register_*``
+and ``register_time_all`` set them (reference ``i2vgen-xl/pnp_utils.py:48-166, 706-715, 889-897, 1031-1037,
+1099-1105, 1157-1159``) -- but every node is a plain Python object holding packed fp16 weights, and every
+computation is a libmvoc_hip kernel (``mvoc_amd.ops``).  There is no torch.nn / MIOpen / rocBLAS on this path.
+
+Layout: activations are channels-last rows ``[B*F*H*W, C]`` for the whole network: spatial
+transformers, temporal transformers, 3x3 convs and temporal convs all consume it directly, so none of the
+reference's permute/reshape copies exist.  ``torch.cat([x, skip], 1)`` is never materialised (two-source
+gathers), Upsample2D is folded into the following conv's gather, q/k/v projections are one fused GEMM whose
+output the attention kernels read through strides, GEGLU / bias / time-embedding add / residual adds live in
+GEMM epilogues.
+
+Forward entry points follow the reference:
+  * ``forward``      -- stock ``I2VGenXLUNet.forward`` call protocol (``pipeline_i2vgen_xl.py:1173-1182, 1952-1961``)
+  * ``forward_ext``  -- ``I2VGenXLUnetExtension.forward`` (``pipeline_i2vgen_xl.py:109-362``), adds
+                        ``image_latents_first`` and ``multi_frame_guidance``
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .ops import ACT_GEGLU, ACT_NONE, ACT_SILU
+from .unet_spec import UNetConfig, param_shapes
+
+H16 = torch.float16
+
+
+def _pad_rows(w, mult=32):
+    n = w.shape[0]
+    if n % mult == 0:
+        return w.contiguous()
+    out = torch.zeros((n + mult - n % mult,) + tuple(w.shape[1:]), dtype=w.dtype, device=w.device)
+    out[:n] = w
+    return out
+
+
+def _pad_cols(w, mult=32):
+    k = w.shape[1]
+    if k % mult == 0:
+        return w.contiguous()
+    out = torch.zeros((w.shape[0], k + mult - k % mult), dtype=w.dtype, device=w.device)
+    out[:, :k] = w
+    return out
+
+
+def pack_conv3x3(w):
+    """[Cout, Cin, 3, 3] -> [Cout_pad32, Kpad32] with k = (ky*3+kx)*Cin + c"""
+    co, ci = w.shape[0], w.shape[1]
+    return _pad_rows(_pad_cols(w.permute(0, 2, 3, 1).reshape(co, 9 * ci)))
+
+
+def pack_conv3x3_small(w):
+    """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] for the direct small-channel conv"""
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def pack_tconv(w):
+    """[Cout, Cin, 3, 1, 1] -> [Cout, 3*Cin] with k = tap*Cin + c"""
+    co, ci = w.shape[0], w.shape[1]
+    return w.reshape(co, ci, 3).permute(0, 2, 1).reshape(co, 3 * ci).contiguous()
+
+
+def pack_geglu(w, b):
+    """GEGLU proj [2*inner, C]: interleave value/gate rows in blocks of 32 so a wave's tile pair holds both."""
+    inner = w.shape[0] // 2
+    idx = torch.arange(2 * inner, device=w.device)
+    blk, s, i = idx // 64, (idx // 32) % 2, idx % 32
+    src = s * inner + blk * 32 + i
+    return w[src].contiguous(), b[src].contiguous()
+
+
+class Hookable:
+    """carrier of the reference's per-site hook state"""
+
+    def __init__(self):
+        self.t = None
+        self.mask = None
+        self.injection_schedule = None
+        self.inject_background = False
+
+    def injecting(self):
+        s = self.injection_schedule
+        if s is None or self.t is None:
+            return False
+        if self.t == 1000:
+            return True
+        if isinstance(s, torch.Tensor):
+            return bool((s == self.t).any().item()) if s.numel() else False
+        return self.t in s
+
+
+class Processor(Hookable):
+    pass
+
+
+class Linear:
+    def __init__(self, w, b=None):
+        self.n = w.shape[0]
+        self.w = _pad_rows(w.to(H16))
+        self.b = None
+        if b is not None:
+            self.b = torch.zeros(self.w.shape[0], dtype=H16, device=w.device)
+            self.b[:self.n] = b.to(H16)
+
+    def __call__(self, x, **kw):
+        return ops.linear(x, self.w, self.b, n_store=self.n, **kw)
+
+
+class Attention:
+    def __init__(self, sd, prefix, heads, cross):
+        self.heads = heads
+        self.cross = cross
+        self.processor = Processor()
+        g = lambda k: sd[prefix + k].to(H16)
+        if cross:
+            self.to_q = Linear(g(".to_q.weight"))
+            self.to_kv = Linear(torch.cat([g(".to_k.weight"), g(".to_v.weight")], 0))
+        else:
+            self.to_qkv = Linear(torch.cat([g(".to_q.weight"), g(".to_k.weight"), g(".to_v.weight")], 0))
+        self.to_out = Linear(g(".to_out.0.weight"), g(".to_out.0.bias"))
+        self.inner = g(".to_q.weight").shape[0]
+
+
+class BasicTransformerBlock:
+    def __init__(self, sd, prefix, dim, heads, cross):
+        g = lambda k: sd[prefix + k].to(H16).contiguous()
+        self.norm1 = (g(".norm1.weight"), g(".norm1.bias"))
+        self.norm2 = (g(".norm2.weight"), g(".norm2.bias"))
+        self.norm3 = (g(".norm3.weight"), g(".norm3.bias"))
+        self.attn1 = Attention(sd, prefix + ".attn1", heads, False)
+        self.attn2 = Attention(sd, prefix + ".attn2", heads, cross)
+        w, b = pack_geglu(g(".ff.net.0.proj.weight"), g(".ff.net.0.proj.bias"))
+        self.ff1_w, self.ff1_b = w, b
+        self.ff2 = Linear(g(".ff.net.2.weight"), g(".ff.net.2.bias"))
+        self.dim = dim
+
+
+class _TransformerBase:
+    def __init__(self, sd, prefix, cin, heads, groups, cross):
+        g = lambda k: sd[prefix + k].to(H16).contiguous()
+        self.norm = (g(".norm.weight"), g(".norm.bias"))
+        self.groups = groups
+        self.proj_in = Linear(g(".proj_in.weight"), g(".proj_in.bias"))
+        self.proj_out = Linear(g(".proj_out.weight"), g(".proj_out.bias"))
+        inner = self.proj_in.n
+        self.transformer_blocks = [BasicTransformerBlock(sd, prefix + ".transformer_blocks.0", inner, heads, cross)]
+        self.heads = heads
+
+
+class Transformer2DModel(_TransformerBase):
+    """``pnp_utils.py:387-548`` (+ ``:222-346``, ``:565-704``): GN -> proj_in -> [LN, self-attn(+PnP Q/K injection),
+    LN, cross-attn, LN, GEGLU ff] -> proj_out + residual."""
+
+    def __init__(self, sd, prefix, cin, heads, groups):
+        super().__init__(sd, prefix, cin, heads, groups, True)
+
+    def forward(self, eng, x, geo, ctx):
+        B, F, H, W = geo
+        hw, nimg = H * W, B * F
+        blk = self.transformer_blocks[0]
+        h = ops.groupnorm(x, *self.norm, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-6, silu=False)
+        h = self.proj_in(h)
+        c = blk.dim
+        # self-attention over the H*W tokens of each image
+        n = ops.layernorm(h, *blk.norm1)
+        qkv = blk.attn1.to_qkv(n)
+        q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+        proc = blk.attn1.processor
+        if proc.injecting():
+            masks = eng.device_masks(proc.mask)[1]  # bool masks as {0,1} fp16
+            ld = qkv.stride(0)
+            ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
+                                 f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
+        a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
+        h = blk.attn1.to_out(a, resid=h)
+        # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
+        n = ops.layernorm(h, *blk.norm2)
+        q2 = blk.attn2.to_q(n)
+        kv = blk.attn2.to_kv(ctx.tokens)
+        a = ops.flash_attn(q2, kv[:, :c], kv[:, c:], nbatch=nimg, heads=self.heads, tq=hw, tk=ctx.length,
+                           kv_bdiv=ctx.frames_per_ctx)
+        h = blk.attn2.to_out(a, resid=h)
+        n = ops.layernorm(h, *blk.norm3)
+        f1 = ops.linear(n, blk.ff1_w, blk.ff1_b, act=ACT_GEGLU)
+        h = blk.ff2(f1, resid=h)
+        return self.proj_out(h, resid=x)
+
+
+class TransformerTemporalModel(_TransformerBase):
+    """``pnp_utils.py:170-220`` (+ ``:720-887``): 5-D GroupNorm (statistics over frames too), then a transformer
+    block whose two attentions both run over the frame axis of each pixel."""
+
+    def __init__(self, sd, prefix, cin, heads, groups):
+        super().__init__(sd, prefix, cin, heads, groups, False)
+
+    def forward(self, eng, x, geo):
+        B, F, H, W = geo
+        hw = H * W
+        blk = self.transformer_blocks[0]
+        h = ops.groupnorm(x, *self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, silu=False)
+        h = self.proj_in(h)
+        c = blk.dim
+        for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
+            n = ops.layernorm(h, *norm)
+            qkv = attn.to_qkv(n)
+            q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+            proc = attn.processor
+            if attn is blk.attn1 and proc.injecting():
+                masks = eng.device_masks(proc.mask)[0]  # soft float masks, channel 0
+                ld = qkv.stride(0)
+                ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
+                                     f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
+            a = ops.temporal_attn(q, k, v, nsample=B, frames=F, hw=hw, heads=self.heads)
+            h = attn.to_out(a, resid=h)
+        n = ops.layernorm(h, *blk.norm3)
+        f1 = ops.linear(n, blk.ff1_w, blk.ff1_b, act=ACT_GEGLU)
+        h = blk.ff2(f1, resid=h)
+        return self.proj_out(h, resid=x)
+
+
+class ResnetBlock2D(Hookable):
+    """``pnp_utils.py:902-1020``.  The feature injection sits between conv2 and the shortcut add."""
+
+    def __init__(self, sd, prefix, groups):
+        super().__init__()
+        g = lambda k: sd[prefix + k].to(H16).contiguous()
+        self.groups = groups
+        self.norm1 = (g(".norm1.weight"), g(".norm1.bias"))
+        self.norm2 = (g(".norm2.weight"), g(".norm2.bias"))
+        self.conv1_w, self.conv1_b = pack_conv3x3(g(".conv1.weight")), g(".conv1.bias")
+        self.conv2_w, self.conv2_b = pack_conv3x3(g(".conv2.weight")), g(".conv2.bias")
+        self.time_emb_proj = Linear(g(".time_emb_proj.weight"), g(".time_emb_proj.bias"))
+        self.cout = self.conv1_b.shape[0]
+        self.conv_shortcut = None
+        if prefix + ".conv_shortcut.weight" in sd:
+            w = g(".conv_shortcut.weight")
+            self.conv_shortcut = Linear(w.reshape(w.shape[0], w.shape[1]), g(".conv_shortcut.bias"))
+
+    def forward(self, eng, x, skip, temb_act, geo):
+        B, F, H, W = geo
+        hw, nimg = H * W, B * F
+        h = ops.groupnorm(x, *self.norm1, x2=skip, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5,
+                          silu=True)
+        tproj = self.time_emb_proj(temb_act)  # [B, Cout]; identical for all frames of a sample
+        h, _, _ = ops.conv3x3(h, self.conv1_w, self.conv1_b, nimg=nimg, h=H, wd=W, rowadd=tproj, rowadd_div=F * hw,
+                              n_store=self.cout)
+        h = ops.groupnorm(h, *self.norm2, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5, silu=True)
+        if self.injecting():
+            h, _, _ = ops.conv3x3(h, self.conv2_w, self.conv2_b, nimg=nimg, h=H, wd=W, n_store=self.cout)
+            eng.inject_features(h, self.mask, geo, self.cout)
+            if self.conv_shortcut is not None:
+                return self.conv_shortcut(x, x2=skip, resid=h)
+            return ops.add(x, h)
+        if self.conv_shortcut is not None:
+            sc = self.conv_shortcut(x, x2=skip)
+        else:
+            sc = x
+        out, _, _ = ops.conv3x3(h, self.conv2_w, self.conv2_b, nimg=nimg, h=H, wd=W, resid=sc, n_store=self.cout)
+        return out
+
+
+class TemporalConvLayer(Hookable):
+    """``pnp_utils.py:1042-1088``: 4 x (GN over the whole video, SiLU, Conv3d(3,1,1)) + identity; injection after."""
+
+    def __init__(self, sd, prefix, groups):
+        super().__init__()
+        g = lambda k: sd[prefix + k].to(H16).contiguous()
+        self.groups = groups
+        self.stages = []
+        for i, ci in ((1, 2), (2, 3), (3, 3), (4, 3)):
+            self.stages.append(((g(f".conv{i}.0.weight"), g(f".conv{i}.0.bias")),
+                                pack_tconv(g(f".conv{i}.{ci}.weight")), g(f".conv{i}.{ci}.bias")))
+
+    def forward(self, eng, x, geo):
+        B, F, H, W = geo
+        hw = H * W
+        h = x
+        for i, (norm, w, b) in enumerate(self.stages):
+            h = ops.groupnorm(h, *norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-5, silu=True)
+            h = ops.tconv3(h, w, b, nvid=B, frames=F, hw=hw, resid=x if i == 3 else None)
+        if self.injecting():
+            eng.inject_features(h, self.mask, geo, h.shape[1])
+        return h
+
+
+class Upsample2D:
+    def __init__(self, sd, prefix):
+        self.w = pack_conv3x3(sd[prefix + ".conv.weight"].to(H16))
+        self.b = sd[prefix + ".conv.bias"].to(H16).contiguous()
+
+    def forward(self, x, geo, size=None):
+        B, F, H, W = geo
+        up = size if size is not None else (2 * H, 2 * W)
+        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, upsample_to=tuple(up), n_store=self.b.shape[0])
+        return out, (B, F, ho, wo)
+
+
+class Downsample2D:
+    def __init__(self, sd, prefix):
+        self.w = pack_conv3x3(sd[prefix + ".conv.weight"].to(H16))
+        self.b = sd[prefix + ".conv.bias"].to(H16).contiguous()
+
+    def forward(self, x, geo):
+        B, F, H, W = geo
+        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, stride=2, n_store=self.b.shape[0])
+        return out, (B, F, ho, wo)
+
+
+class Block:
+    def __init__(self):
+        self.resnets, self.temp_convs, self.attentions, self.temp_attentions = [], [], [], []
+        self.downsamplers = None
+        self.upsamplers = None
+        self.has_cross_attention = False
+
+
+class ConvOut(Hookable):
+    def __init__(self, w, b):
+        super().__init__()
+        self.w = pack_conv3x3(w.to(H16))
+        self.b = torch.zeros(self.w.shape[0], dtype=H16, device=w.device)
+        self.b[:b.shape[0]] = b.to(H16)
+        self.cout = b.shape[0]
+
+
+class Context:
+    def __init__(self, tokens, length, frames_per_ctx):
+        self.tokens, self.length, self.frames_per_ctx = tokens, length, frames_per_ctx
+
+
+class I2VGenXLUNet:
+    """MI355X engine with the reference UNet's call protocol."""
+
+    def __init__(self, config=None, device="cuda:0"):
+        self.config = UNetConfig.from_any(config) if config is not None else UNetConfig()
+        self.device = torch.device(device)
+        self.dtype = H16
+        self.num_upsamplers = len(self.config.block_out_channels) - 1
+        self._mask_cache = (None, None)
+        self._loaded = False
+
+    # ---- weights --------------------------------------------------------------------------------
+    def expected_shapes(self):
+        return param_shapes(self.config)
+
+    def load_state_dict(self, sd):
+        """sd: diffusers ``I2VGenXLUNet`` state_dict (any float dtype, any device)."""
+        exp = self.expected_shapes()
+        missing = [k for k in exp if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict is missing {len(missing)} keys, e.g. {missing[:3]}")
+        for k, shp in exp.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected shape {shp}, got {tuple(sd[k].shape)}")
+        sd = {k: sd[k].detach().to(self.device, H16) for k in exp}
+        self._build(sd)
+        return self
+
+    def init_random(self, seed=8888):
+        """Synthetic weights of the exact architecture, generated on the device (no checkpoint in this
+        environment): U(+-1/sqrt(fan_in)) matrices, norm gains ~1, residual-branch output layers damped."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        sd = OrderedDict()
+        damp = ("proj_out.weight", "conv2.weight", "conv4.3.weight", "to_out.0.weight", "ff.net.2.weight")
+        for k, shp in self.expected_shapes().items():
+            if len(shp) >= 2:
+                fan_in = 1
+                for s in shp[1:]:
+                    fan_in *= s
+                t = (torch.rand(shp, generator=g, device=self.device) * 2 - 1) * (1.0 / math.sqrt(fan_in))
+                if k.endswith(damp):
+                    t *= 0.5
+            elif "norm" in k or any(f".conv{i}.0." in k for i in (1, 2, 3, 4)):
+                r = torch.rand(shp, generator=g, device=self.device) * 2 - 1
+                t = 1.0 + 0.1 * r if k.endswith("weight") else 0.1 * r
+            else:
+                t = 0.05 * (torch.rand(shp, generator=g, device=self.device) * 2 - 1)
+            sd[k] = t.to(H16)
+        self._build(sd)
+        return self
+
+    def _build(self, sd):
+        cfg = self.config
+        boc, hd, g = cfg.block_out_channels, cfg.attention_head_dim, cfg.norm_num_groups
+        f16 = lambda k: sd[k].to(H16).contiguous()
+        # stem
+        self.conv_in = ConvOut(sd["conv_in.weight"], sd["conv_in.bias"])  # Hookable (register_time_all sets t/mask on it)
+        self.transformer_in = TransformerTemporalModel(sd, "transformer_in", boc[0], cfg.transformer_in_heads, g)
+        self.proj_in_convs = [(pack_conv3x3_small(f16(f"image_latents_proj_in.{i}.weight")),
+                               f16(f"image_latents_proj_in.{i}.bias")) for i in (0, 2, 4)]
+        e = "image_latents_temporal_encoder"
+        blob = [f16(f"{e}.norm1.weight"), f16(f"{e}.norm1.bias"), f16(f"{e}.attn1.to_q.weight"), f16(f"{e}.attn1.to_k.weight"),
+                f16(f"{e}.attn1.to_v.weight"), f16(f"{e}.attn1.to_out.0.weight"), f16(f"{e}.attn1.to_out.0.bias"),
+                f16(f"{e}.ff.net.0.proj.weight"), f16(f"{e}.ff.net.0.proj.bias"), f16(f"{e}.ff.net.2.weight"),
+                f16(f"{e}.ff.net.2.bias")]
+        self.enc4_params = torch.cat([t.reshape(-1) for t in blob]).contiguous()
+        assert self.enc4_params.numel() == 4 + 4 + 32 * 4 + 4 + 64 + 16 + 64 + 4
+        self.ctx_convs = [(pack_conv3x3_small(f16(f"image_latents_context_embedding.{i}.weight")),
+                           f16(f"image_latents_context_embedding.{i}.bias")) for i in (0, 3, 5)]
+        self.time_embedding = (Linear(f16("time_embedding.linear_1.weight"), f16("time_embedding.linear_1.bias")),
+                               Linear(f16("time_embedding.linear_2.weight"), f16("time_embedding.linear_2.bias")))
+        self.fps_embedding = (Linear(f16("fps_embedding.0.weight"), f16("fps_embedding.0.bias")),
+                              Linear(f16("fps_embedding.2.weight"), f16("fps_embedding.2.bias")))
+        self.context_embedding = (Linear(f16("context_embedding.0.weight"), f16("context_embedding.0.bias")),
+                                  Linear(f16("context_embedding.2.weight"), f16("context_embedding.2.bias")))
+        # blocks
+        self.down_blocks = []
+        for i, t in enumerate(cfg.down_block_types):
+            b = Block()
+            p = f"down_blocks.{i}"
+            for j in range(cfg.layers_per_block):
+                b.resnets.append(ResnetBlock2D(sd, f"{p}.resnets.{j}", g))
+                b.temp_convs.append(TemporalConvLayer(sd, f"{p}.temp_convs.{j}", g))
+                if t == "CrossAttnDownBlock3D":
+                    b.has_cross_attention = True
+                    b.attentions.append(Transformer2DModel(sd, f"{p}.attentions.{j}", boc[i], boc[i] // hd, g))
+                    b.temp_attentions.append(TransformerTemporalModel(sd, f"{p}.temp_attentions.{j}", boc[i], boc[i] // hd, g))
+            if i != len(boc) - 1:
+                b.downsamplers = [Downsample2D(sd, f"{p}.downsamplers.0")]
+            self.down_blocks.append(b)
+        m = Block()
+        m.has_cross_attention = True
+        for j in range(2):
+            m.resnets.append(ResnetBlock2D(sd, f"mid_block.resnets.{j}", g))
+            m.temp_convs.append(TemporalConvLayer(sd, f"mid_block.temp_convs.{j}", g))
+        m.attentions.append(Transformer2DModel(sd, "mid_block.attentions.0", boc[-1], boc[-1] // hd, g))
+        m.temp_attentions.append(TransformerTemporalModel(sd, "mid_block.temp_attentions.0", boc[-1], boc[-1] // hd, g))
+        self.mid_block = m
+        self.up_blocks = []
+        rev = list(reversed(boc))
+        for i, t in enumerate(cfg.up_block_types):
+            b = Block()
+            p = f"up_blocks.{i}"
+            for j in range(cfg.layers_per_block + 1):
+                b.resnets.append(ResnetBlock2D(sd, f"{p}.resnets.{j}", g))
+                b.temp_convs.append(TemporalConvLayer(sd, f"{p}.temp_convs.{j}", g))
+                if t == "CrossAttnUpBlock3D":
+                    b.has_cross_attention = True
+                    b.attentions.append(Transformer2DModel(sd, f"{p}.attentions.{j}", rev[i], rev[i] // hd, g))
+                    b.temp_attentions.append(TransformerTemporalModel(sd, f"{p}.temp_attentions.{j}", rev[i], rev[i] // hd, g))
+            if i != len(boc) - 1:
+                b.upsamplers = [Upsample2D(sd, f"{p}.upsamplers.0")]
+            self.up_blocks.append(b)
+        self.conv_norm_out = (f16("conv_norm_out.weight"), f16("conv_norm_out.bias"))
+        self.conv_out = ConvOut(sd["conv_out.weight"], sd["conv_out.bias"])
+        self._loaded = True
+
+    # ---- PnP helpers ------------------------------------------------------------------------------
+    def device_masks(self, mask_list):
+        """list of (float [1,4,F,h,w], bool [1,4,F,h,w]) pairs (``register_time_all``'s ``mask``) ->
+        (soft fp16 [nobj,F,h,w] from channel 0, hard {0,1} fp16 [nobj,F,h,w]); cached per mask list object."""
+        key = tuple((m[0].data_ptr(), m[1].data_ptr()) for m in mask_list)
+        if self._mask_cache[0] != key:
+            soft = torch.stack([m[0].reshape(-1, *m[0].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
+            hard = torch.stack([m[1].reshape(-1, *m[1].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
+            self._mask_cache = (key, (soft, hard))
+        return self._mask_cache[1]
+
+    def inject_features(self, h, mask_list, geo, channels):
+        """feature injection (``pnp_utils.py:970-1004, 1059-1082, 1114-1146``): base = chunk 0, bool mask, no resize"""
+        B, F, H, W = geo
+        hard = self.device_masks(mask_list)[1]
+        if hard.shape[2] != H or hard.shape[3] != W:
+            raise RuntimeError(f"feature injection needs masks at the feature resolution {(H, W)}, got "
+                               f"{tuple(hard.shape[2:])} (reference: pnp_utils.py:994-1000 has no resize)")
+        ld = h.stride(0)
+        ops.pnp_blend_tokens(h, hard, frames=F, height=H, width=W, channels=channels, chunk_stride=F * H * W * ld,
+                             f_stride=H * W * ld, p_stride=ld, base_chunk0=True)
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _embeddings(self, timestep, fps, B):
+        if torch.is_tensor(timestep):
+            t = timestep.to(self.device, torch.float32).reshape(-1)
+        else:
+            t = torch.tensor([float(timestep)], dtype=torch.float32, device=self.device)
+        t = t.expand(B).contiguous()
+        f = fps.to(self.device, torch.float32).reshape(-1).expand(B).contiguous()
+        boc0 = self.config.block_out_channels[0]
+        te = ops.timestep_embedding(t, boc0)
+        te = self.time_embedding[1](self.time_embedding[0](te, act=ACT_SILU))
+        fe = ops.timestep_embedding(f, boc0)
+        fe = self.fps_embedding[1](self.fps_embedding[0](fe, act=ACT_SILU))
+        emb = ops.add(te, fe)
+        return ops.act(emb, ACT_SILU)  # every resnet applies SiLU before its time_emb_proj
+
+    def _context(self, image_latents, image_embeddings, encoder_hidden_states, F, multi_frame_guidance):
+        """77 text + 64 image-latent + 4 CLIP-image tokens per sample (per frame with multi_frame_guidance).
+        Without multi-frame guidance the reference recomputes the same context F times (``pipeline_i2vgen_xl.py:211``
+        loops over frames reading frame 0); here it is computed once and shared through kv_bdiv."""
+        cfg = self.config
+        B = image_latents.shape[0]
+        h, w = image_latents.shape[-2:]
+        frames = list(range(F)) if multi_frame_guidance else [0]
+        nf = len(frames)
+        lat = image_latents[:, :, frames].to(self.device, H16)  # [B,4,nf,h,w]
+        tok = torch.empty((B * nf * h * w, 4), dtype=H16, device=self.device)
+        ops.ncfhw_to_tokens(lat, tok)
+        (w0, b0), (w1, b1), (w2, b2) = self.ctx_convs
+        x, _, _ = ops.conv3x3_small(tok, w0, b0, nimg=B * nf, h=h, wd=w, cin=4, cout=w0.shape[0], silu=True)
+        P = cfg.context_pool
+        x = ops.adaptive_avgpool(x, nimg=B * nf, h=h, w=w, c=w0.shape[0], oh=P, ow=P)
+        x, h1, w1_ = ops.conv3x3_small(x, w1, b1, nimg=B * nf, h=P, wd=P, cin=w0.shape[0], cout=w1.shape[0], stride=2, silu=True)
+        x, h2, w2_ = ops.conv3x3_small(x, w2, b2, nimg=B * nf, h=h1, wd=w1_, cin=w1.shape[0], cout=w2.shape[0], stride=2)
+        nlat = h2 * w2_
+        ie = image_embeddings.to(self.device, H16)
+        if ie.dim() == 2:
+            ie = ie[:, None]
+        ie = ie[:, frames].reshape(B * nf, -1).contiguous()
+        it = self.context_embedding[1](self.context_embedding[0](ie, act=ACT_SILU))  # [B*nf, 4*ctx]
+        ntext = encoder_hidden_states.shape[1]
+        L = ntext + nlat + cfg.in_channels
+        ctx = torch.empty((B, nf, L, cfg.cross_attention_dim), dtype=H16, device=self.device)
+        ctx[:, :, :ntext] = encoder_hidden_states.to(self.device, H16)[:, None]
+        ctx[:, :, ntext:ntext + nlat] = x.view(B, nf, nlat, -1)
+        ctx[:, :, ntext + nlat:] = it.view(B, nf, cfg.in_channels, -1)
+        return Context(ctx.view(B * nf * L, -1), L, 1 if multi_frame_guidance else F)
+
+    def forward(self, sample, timestep, fps, image_latents, image_embeddings=None, encoder_hidden_states=None,
+                cross_attention_kwargs=None, return_dict=True, **_):
+        out = self._forward(sample, timestep, fps, image_latents, image_latents, image_embeddings, encoder_hidden_states, False)
+        return (out,)
+
+    __call__ = forward
+
+    def forward_ext(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings=None,
+                    encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
+                    multi_frame_guidance=False, return_dict=True):
+        out = self._forward(sample, timestep, fps, image_latents_first, image_latents, image_embeddings,
+                            encoder_hidden_states, multi_frame_guidance)
+        return (out,)
+
+    @torch.no_grad()
+    def _forward(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings, encoder_hidden_states,
+                 multi_frame_guidance):
+        if not self._loaded:
+            raise RuntimeError("I2VGenXLUNet: load_state_dict() or init_random() first")
+        cfg = self.config
+        sample = sample.to(self.device, H16)
+        B, C, F, H, W = sample.shape
+        hw = H * W
+        up_factor = 2 ** self.num_upsamplers
+        forward_upsample_size = any(s % up_factor != 0 for s in (H, W))
+        temb_act = self._embeddings(timestep, fps, B)
+        ctx = self._context(image_latents, image_embeddings, encoder_hidden_states, F, multi_frame_guidance)
+
+        # stem: image_latents_proj_in -> temporal encoder -> cat with sample -> conv_in -> transformer_in
+        il = torch.empty((B * F * hw, 4), dtype=H16, device=self.device)
+        ops.ncfhw_to_tokens(image_latents_first.to(self.device, H16), il)
+        for i, (w_, b_) in enumerate(self.proj_in_convs):
+            il, _, _ = ops.conv3x3_small(il, w_, b_, nimg=B * F, h=H, wd=W, cin=w_.shape[3], cout=w_.shape[0], silu=i < 2)
+        x8 = torch.empty((B * F * hw, 8), dtype=H16, device=self.device)
+        ops.ncfhw_to_tokens(sample, x8, coff=0)
+        ops.temporal_encoder4(il, self.enc4_params, x8, b=B, f=F, hw=hw, coff=4)
+        geo = (B, F, H, W)
+        x, _, _ = ops.conv3x3(x8, self.conv_in.w, self.conv_in.b, nimg=B * F, h=H, wd=W, n_store=self.conv_in.cout)
+        x = self.transformer_in.forward(self, x, geo)
+
+        skips = [(x, geo)]
+        for blk in self.down_blocks:
+            for j, rn in enumerate(blk.resnets):
+                x = rn.forward(self, x, None, temb_act, geo)
+                x = blk.temp_convs[j].forward(self, x, geo)
+                if blk.has_cross_attention:
+                    x = blk.attentions[j].forward(self, x, geo, ctx)
+                    x = blk.temp_attentions[j].forward(self, x, geo)
+                skips.append((x, geo))
+            if blk.downsamplers is not None:
+                x, geo = blk.downsamplers[0].forward(x, geo)
+                skips.append((x, geo))
+        m = self.mid_block
+        x = m.resnets[0].forward(self, x, None, temb_act, geo)
+        x = m.temp_convs[0].forward(self, x, geo)
+        x = m.attentions[0].forward(self, x, geo, ctx)
+        x = m.temp_attentions[0].forward(self, x, geo)
+        x = m.resnets[1].forward(self, x, None, temb_act, geo)
+        x = m.temp_convs[1].forward(self, x, geo)
+
+        for i, blk in enumerate(self.up_blocks):
+            n = len(blk.resnets)
+            res, skips = skips[-n:], skips[:-n]
+            upsample_size = None
+            if i != len(self.up_blocks) - 1 and forward_upsample_size:
+                upsample_size = skips[-1][1][2:]
+            for j, rn in enumerate(blk.resnets):
+                skip, sgeo = res[-1]
+                res = res[:-1]
+                assert sgeo == geo, (sgeo, geo)
+                x = rn.forward(self, x, skip, temb_act, geo)
+                x = blk.temp_convs[j].forward(self, x, geo)
+                if blk.has_cross_attention:
+                    x = blk.attentions[j].forward(self, x, geo, ctx)
+                    x = blk.temp_attentions[j].forward(self, x, geo)
+            if blk.upsamplers is not None:
+                x, geo = blk.upsamplers[0].forward(x, geo, upsample_size)
+
+        h = ops.groupnorm(x, *self.conv_norm_out, nsample=B * F, rows_per_sample=hw, groups=cfg.norm_num_groups, eps=1e-5,
+                          silu=True)
+        co = self.conv_out
+        y, _, _ = ops.conv3x3(h, co.w, co.b, nimg=B * F, h=H, wd=W, n_store=co.cout)
+        if co.injecting():
+            # conv_out writes cout (4) channels into a [rows, 4] buffer: the token kernel needs channels % 8 == 0,
+            # so this tiny tensor goes through the NCHW form of the kernel on the boundary layout instead
+            out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)  # [B,C,F,h,w]
+            nchw = out.permute(0, 2, 1, 3, 4).reshape(B * F, co.cout, H, W).contiguous()
+            ops.pnp_blend_nchw(nchw, self.device_masks(co.mask)[1], frames=F, base_chunk0=True)
+            return nchw.reshape(B, F, co.cout, H, W).permute(0, 2, 1, 3, 4).contiguous()
+        return ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)

@@ -1,0 +1,137 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares, the host logic
+(parameter table, schedulers, hook registration) agrees with the oracle.  No kernel is launched here."""
+import os
+import re
+import types
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from mvoc_amd import _ffi
+    hdr = open(os.path.join(REPO, "include", "mvoc_hip.h")).read()
+    declared = set(re.findall(r"\b(mvoc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mvoc_gemm_desc", "mvoc_attn_desc", "mvoc_tattn_desc", "mvoc_gn_desc", "mvoc_pnp_desc"}
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(_ffi.lib, name), f"libmvoc_hip.so does not export {name}"
+        assert name in _ffi.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_ffi.SIGNATURES) == declared
+    assert _ffi.lib.mvoc_version() == 100
+    assert _ffi.lib.mvoc_groupnorm_workspace_bytes(16, 4096, 320, 32) > 0
+
+
+def test_struct_layouts_match_header():
+    """field order of the ctypes structs == field order in the header (both are read by the same kernel launcher)"""
+    from mvoc_amd import _ffi
+    hdr = open(os.path.join(REPO, "include", "mvoc_hip.h")).read()
+    for cname, cls in (("mvoc_gemm_desc", _ffi.GemmDesc), ("mvoc_attn_desc", _ffi.AttnDesc), ("mvoc_tattn_desc", _ffi.TAttnDesc),
+                       ("mvoc_gn_desc", _ffi.GnDesc), ("mvoc_pnp_desc", _ffi.PnpDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(void|int64_t|int32_t|size_t|float)\s*\*?", "", decl)
+            names += [n.strip().lstrip("*") for n in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_ops_refuse_cpu_tensors():
+    from mvoc_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.linear(torch.zeros(4, 32, dtype=torch.float16), torch.zeros(32, 32, dtype=torch.float16))
+
+
+def test_param_table_matches_oracle_tree():
+    from oracle import unet_ref as U
+    from mvoc_amd.unet_spec import UNetConfig, param_shapes
+    for ocfg in (U.UNetConfig(), U.UNetConfig.small4(), U.UNetConfig.tiny()):
+        with torch.device("meta"):
+            m = U.I2VGenXLUNet(ocfg)
+        sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert sd == dict(param_shapes(UNetConfig.from_any(ocfg.to_dict())))
+
+
+def test_schedulers_match_oracle_and_reference_comment():
+    from oracle import sched_ref
+    from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    s, r = DDIMScheduler(), sched_ref.DDIMSchedulerRef()
+    assert torch.equal(s.alphas_cumprod, r.alphas_cumprod)
+    s.set_timesteps(50)
+    r.set_timesteps(50)
+    assert torch.equal(s.timesteps, r.timesteps)
+    # i2vgen-xl/configs/group_composite/template.yaml:43: "0 for 981, 3 for 921, 9 for 801, 20 for 581 if n_steps=50"
+    assert [int(s.timesteps[i]) for i in (0, 3, 9, 20)] == [981, 921, 801, 581]
+    i, ri = DDIMInverseScheduler(), sched_ref.DDIMInverseSchedulerRef()
+    i.set_timesteps(500)
+    ri.set_timesteps(500)
+    assert torch.equal(i.timesteps, ri.timesteps)
+    assert set(s.timesteps.tolist()) <= set(i.timesteps.tolist())  # 500-step inversion feeds 50-step composition
+    # coefficient rows reproduce the oracle's scalars
+    for t in (981, 501, 1):
+        sa, sb, sp, sq, g = s.coefficients(t, 9.0)
+        a_t, a_p = r.alphas_cumprod[t], (r.alphas_cumprod[t - 20] if t - 20 >= 0 else r.final_alpha_cumprod)
+        assert sa == float(a_t ** 0.5) and sb == float((1 - a_t) ** 0.5) and sp == float(a_p ** 0.5) and g == 9.0
+    import copy
+    s.timesteps = s.timesteps[3:]
+    c = copy.deepcopy(s)
+    assert torch.equal(c.timesteps, s.timesteps) and c is not s
+
+
+def _cpu_engine():
+    from mvoc_amd.unet import I2VGenXLUNet
+    from oracle import unet_ref as U
+    o = U.I2VGenXLUNet(U.UNetConfig.small4())
+    eng = I2VGenXLUNet(o.config.to_dict(), device="cpu")
+    eng.load_state_dict(o.state_dict())  # packing is plain tensor plumbing and works without a GPU
+    return eng
+
+
+def test_hook_registration_sites_and_state():
+    from mvoc_amd import pnp_utils
+    from mvoc_amd.schedulers import DDIMScheduler
+    eng = _cpu_engine()
+    pipe = types.SimpleNamespace(unet=eng)
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    conv_t, attn_t = s.timesteps[:5], s.timesteps[:25]
+    pnp_utils.modify_diffuser_attention_forward(eng)
+    pnp_utils.register_temp_attention_pnp(pipe, attn_t, False)
+    pnp_utils.register_spatial_attention_pnp(pipe, attn_t, True)
+    pnp_utils.register_temp_conv_injection(pipe, conv_t)
+    pnp_utils.register_out_conv_injection(pipe, conv_t)
+    pnp_utils.register_resnet_injection(pipe, conv_t)
+    masks = [(torch.zeros(1, 4, 2, 8, 8, dtype=torch.float16), torch.zeros(1, 4, 2, 8, 8, dtype=torch.bool))] * 2
+
+    def sites():
+        spa, tmp = [], []
+        for bi, blk in enumerate(eng.up_blocks):
+            for j, tr in enumerate(blk.attentions):
+                if tr.transformer_blocks[0].attn1.processor.injecting():
+                    spa.append((bi, j))
+            for j, tr in enumerate(blk.temp_attentions):
+                if tr.transformer_blocks[0].attn1.processor.injecting():
+                    tmp.append((bi, j))
+        feat = [(bi, j) for bi, blk in enumerate(eng.up_blocks) for j, r in enumerate(blk.resnets) if r.injecting()]
+        tconv = [(bi, j) for bi, blk in enumerate(eng.up_blocks) for j, r in enumerate(blk.temp_convs) if r.injecting()]
+        return spa, tmp, feat, tconv, eng.conv_out.injecting()
+
+    expect_attn = [(1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2)]  # pnp_utils.py:706, 889
+    expect_feat = [(3, 0), (3, 1), (3, 2)]                                          # pnp_utils.py:1031, 1099
+    pnp_utils.register_time_all(pipe, 981, masks)
+    assert sites() == (expect_attn, expect_attn, expect_feat, expect_feat, True)
+    pnp_utils.register_time_all(pipe, 881, masks)  # past the conv schedule (5 steps), inside the attention one
+    assert sites() == (expect_attn, expect_attn, [], [], False)
+    pnp_utils.register_time_all(pipe, 1, masks)
+    assert sites() == ([], [], [], [], False)
+    assert eng.up_blocks[1].attentions[1].transformer_blocks[0].attn1.processor.inject_background is True
+    assert eng.up_blocks[1].temp_attentions[1].transformer_blocks[0].attn1.processor.inject_background is False
+    # attn2 / down / mid processors get t and mask pushed but never inject (no schedule registered there)
+    p = eng.mid_block.attentions[0].transformer_blocks[0].attn2.processor
+    assert p.t == 1 and p.mask is masks and not p.injecting()

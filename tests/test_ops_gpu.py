@@ -1,0 +1,417 @@
+"""GPU parity of every libmvoc_hip op (through the C ABI) against the CPU oracle / the PyTorch CPU primitive the
+reference's diffusers module calls.  Integer/bit-level work (PnP injection, DDIM step, latent fusion) must be
+BIT-EXACT; floating-point kernels are held to the tolerance written in each test."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from mvoc_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.to("cuda", torch.float16).contiguous()
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16)
+
+
+# ---- GEMM family -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("m", [128, 333, 2048])
+def test_linear_exact_integers(ops, tile, m):
+    """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
+    maps (asymmetric data) are checked bit for bit"""
+    g = torch.Generator().manual_seed(tile * 1000 + m)
+    n, k = 320, 96
+    x = torch.randint(-3, 4, (m, k), generator=g).float()
+    w = torch.randint(-3, 4, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    out = ops.linear(dev(x), dev(w), dev(b), tile=tile)
+    ref = x @ w.t() + b
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("n,k", [(320, 320), (640, 1280), (512, 320), (960, 64), (64, 1024)])
+def test_linear_random(ops, n, k):
+    g = torch.Generator().manual_seed(n + k)
+    m = 777
+    x = torch.randn(m, k, generator=g).half()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).half()
+    b = torch.randn(n, generator=g).half()
+    r = torch.randn(m, n, generator=g).half()
+    out = ops.linear(dev(x), dev(w), dev(b), resid=dev(r))
+    ref = (x.float() @ w.float().t() + b.float()).half().float() + r.float()
+    assert rel_l2(out, ref) < 1e-3
+    assert (out.float().cpu() - ref).abs().max() < 2e-2
+
+
+def test_linear_concat_and_acts(ops):
+    g = torch.Generator().manual_seed(5)
+    m, k1, k2, n = 300, 128, 64, 192
+    x1, x2 = torch.randn(m, k1, generator=g).half(), torch.randn(m, k2, generator=g).half()
+    w = (torch.randn(n, k1 + k2, generator=g) / 14).half()
+    b = torch.randn(n, generator=g).half()
+    ref = torch.cat([x1, x2], 1).float() @ w.float().t() + b.float()
+    out = ops.linear(dev(x1), dev(w), dev(b), x2=dev(x2))
+    assert rel_l2(out, ref) < 1e-3
+    out = ops.linear(dev(x1), dev(w), dev(b), x2=dev(x2), act=ops.ACT_SILU)
+    assert rel_l2(out, F.silu(ref.half().float())) < 2e-3
+
+
+def test_linear_geglu(ops):
+    from mvoc_amd.unet import pack_geglu
+    g = torch.Generator().manual_seed(6)
+    m, c, inner = 257, 128, 512
+    x = torch.randn(m, c, generator=g).half()
+    w = (torch.randn(2 * inner, c, generator=g) / math.sqrt(c)).half()
+    b = torch.randn(2 * inner, generator=g).half()
+    y = x.float() @ w.float().t() + b.float()
+    hh, gg = y.half().float().chunk(2, dim=-1)
+    ref = hh * F.gelu(gg).half().float()
+    wp, bp = pack_geglu(dev(w), dev(b))
+    out = ops.linear(dev(x), wp, bp, act=ops.ACT_GEGLU)
+    assert out.shape == (m, inner)
+    assert rel_l2(out, ref) < 2e-3
+
+
+def _nhwc(x):  # [n,c,h,w] -> rows
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+
+
+def _from_rows(r, n, h, w):
+    return r.reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 8, 8, 1), (32, 96, 7, 9, 1), (64, 128, 9, 6, 2), (8, 64, 8, 8, 1)])
+def test_conv3x3(ops, cin, cout, h, w, stride):
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(cin + cout + h)
+    n = 5
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half()
+    b = torch.randn(cout, generator=g).half()
+    ref = F.conv2d(x.float(), wt.float(), b.float(), stride=stride, padding=1)
+    out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, stride=stride, n_store=cout)
+    assert (ho, wo) == tuple(ref.shape[2:])
+    assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
+
+
+def test_conv3x3_concat_temb_resid(ops):
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(11)
+    n, c1, c2, cout, h, w, fr = 6, 64, 32, 64, 6, 5, 3
+    x1, x2 = torch.randn(n, c1, h, w, generator=g).half(), torch.randn(n, c2, h, w, generator=g).half()
+    wt = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / 29).half()
+    b = torch.randn(cout, generator=g).half()
+    temb = torch.randn(n // fr, cout, generator=g).half()  # one row per sample (fr frames each)
+    res = torch.randn(n, cout, h, w, generator=g).half()
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), wt.float(), b.float(), padding=1)
+    ref = ref + temb.float().repeat_interleave(fr, 0)[:, :, None, None] + res.float()
+    out, _, _ = ops.conv3x3(dev(_nhwc(x1)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, x2=dev(_nhwc(x2)),
+                            rowadd=dev(temb), rowadd_div=fr * h * w, resid=dev(_nhwc(res)), n_store=cout)
+    assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("size", [None, (11, 7)])
+def test_conv3x3_upsample(ops, size):
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(12)
+    n, c, h, w = 3, 64, 6, 4
+    x = torch.randn(n, c, h, w, generator=g).half()
+    wt = (torch.randn(c, c, 3, 3, generator=g) / 24).half()
+    b = torch.randn(c, generator=g).half()
+    up = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if size is None else F.interpolate(x.float(), size=size, mode="nearest")
+    ref = F.conv2d(up, wt.float(), b.float(), padding=1)
+    out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w,
+                              upsample_to=size or (2 * h, 2 * w), n_store=c)
+    assert (ho, wo) == tuple(ref.shape[2:])
+    assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("frames", [1, 3, 16])
+def test_tconv3(ops, frames):
+    from mvoc_amd.unet import pack_tconv
+    g = torch.Generator().manual_seed(13 + frames)
+    nb, c, hw = 2, 64, 12
+    x = torch.randn(nb, c, frames, hw, 1, generator=g).half()
+    wt = (torch.randn(c, c, 3, 1, 1, generator=g) / 14).half()
+    b = torch.randn(c, generator=g).half()
+    ref = F.conv3d(x.float(), wt.float(), b.float(), padding=(1, 0, 0)) + x.float()
+    rows = x[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c)
+    out = ops.tconv3(dev(rows), pack_tconv(dev(wt)), dev(b), nvid=nb, frames=frames, hw=hw, resid=dev(rows))
+    got = out.reshape(nb, frames, hw, c).permute(0, 3, 1, 2)[..., None]
+    assert rel_l2(got, ref) < 1.5e-3
+
+
+# ---- attention ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tq,tk,heads,kv_bdiv", [(256, 256, 2, 1), (100, 100, 1, 1), (200, 145, 2, 3), (64, 64, 5, 1), (130, 77, 1, 1)])
+def test_flash_attn(ops, tq, tk, heads, kv_bdiv):
+    g = torch.Generator().manual_seed(tq + tk)
+    nb = 6
+    c = heads * 64
+    qkv = torch.randn(nb * tq, 3 * c, generator=g).half()  # q read through a strided view like the fused qkv GEMM output
+    k = torch.randn((nb // kv_bdiv) * tk, c, generator=g).half()
+    v = torch.randn((nb // kv_bdiv) * tk, c, generator=g).half()
+    dq = dev(qkv)
+    out = ops.flash_attn(dq[:, c:2 * c], dev(k), dev(v), nbatch=nb, heads=heads, tq=tq, tk=tk, kv_bdiv=kv_bdiv)
+    q4 = qkv[:, c:2 * c].float().reshape(nb, tq, heads, 64).transpose(1, 2)
+    k4 = k.float().reshape(nb // kv_bdiv, tk, heads, 64).transpose(1, 2).repeat_interleave(kv_bdiv, 0)
+    v4 = v.float().reshape(nb // kv_bdiv, tk, heads, 64).transpose(1, 2).repeat_interleave(kv_bdiv, 0)
+    ref = F.scaled_dot_product_attention(q4, k4, v4).transpose(1, 2).reshape(nb * tq, c)
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+
+
+def test_flash_attn_large_scores(ops):
+    """spiked keys force big running-max jumps between KV tiles (online-softmax rescale path)"""
+    g = torch.Generator().manual_seed(3)
+    nb, t, heads = 1, 320, 1
+    q = torch.randn(nb * t, 64, generator=g).half()
+    k = torch.randn(nb * t, 64, generator=g).half()
+    v = torch.randn(nb * t, 64, generator=g).half()
+    k[70] = q[5] * 4
+    k[200] = q[5] * 8
+    k[300] = q[9] * 10
+    out = ops.flash_attn(dev(q), dev(k), dev(v), nbatch=nb, heads=heads, tq=t, tk=t)
+    ref = F.scaled_dot_product_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None])[0, 0]
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("frames,heads", [(16, 2), (3, 1), (32, 1), (8, 5)])
+def test_temporal_attn(ops, frames, heads):
+    g = torch.Generator().manual_seed(frames)
+    ns, hw = 3, 21
+    c = heads * 64
+    qkv = torch.randn(ns * frames * hw, 3 * c, generator=g).half()
+    d = dev(qkv)
+    out = ops.temporal_attn(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], nsample=ns, frames=frames, hw=hw, heads=heads)
+
+    def seq(t):  # [ns, F, hw, heads, 64] -> [ns*hw, heads, F, 64]
+        return t.float().reshape(ns, frames, hw, heads, 64).permute(0, 2, 3, 1, 4).reshape(ns * hw, heads, frames, 64)
+
+    ref = F.scaled_dot_product_attention(seq(qkv[:, :c]), seq(qkv[:, c:2 * c]), seq(qkv[:, 2 * c:]))
+    ref = ref.reshape(ns, hw, heads, frames, 64).permute(0, 3, 1, 2, 4).reshape(ns * frames * hw, c)
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+
+
+# ---- norms ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c,groups,rows,nsample,silu", [(320, 32, 64, 5, True), (64, 8, 37, 3, False), (2560, 32, 16, 2, True),
+                                                        (960, 32, 100, 4, True), (128, 8, 4096, 2, False)])
+def test_groupnorm(ops, c, groups, rows, nsample, silu):
+    g = torch.Generator().manual_seed(c + rows)
+    x = (torch.randn(nsample, rows, c, generator=g) * 2 + 0.5).half()
+    gm, bt = (1 + 0.2 * torch.randn(c, generator=g)).half(), (0.2 * torch.randn(c, generator=g)).half()
+    ref = F.group_norm(x.float().permute(0, 2, 1), groups, gm.float(), bt.float(), eps=1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+    out = ops.groupnorm(dev(x.reshape(-1, c)), dev(gm), dev(bt), nsample=nsample, rows_per_sample=rows, groups=groups, eps=1e-5,
+                        silu=silu)
+    assert (out.float().cpu().reshape(nsample, rows, c) - ref).abs().max() < 1.5e-2
+    assert rel_l2(out.reshape(nsample, rows, c), ref) < 2e-3
+
+
+def test_groupnorm_concat(ops):
+    g = torch.Generator().manual_seed(77)
+    c1, c2, groups, rows, ns = 1280, 640, 32, 24, 3  # 60 channels per group: group 21 straddles the two sources
+    x1, x2 = torch.randn(ns, rows, c1, generator=g).half(), (torch.randn(ns, rows, c2, generator=g) * 3).half()
+    gm, bt = (1 + 0.2 * torch.randn(c1 + c2, generator=g)).half(), (0.2 * torch.randn(c1 + c2, generator=g)).half()
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 2).float().permute(0, 2, 1), groups, gm.float(), bt.float(), eps=1e-5)).permute(0, 2, 1)
+    out = ops.groupnorm(dev(x1.reshape(-1, c1)), dev(gm), dev(bt), x2=dev(x2.reshape(-1, c2)), nsample=ns, rows_per_sample=rows,
+                        groups=groups, eps=1e-5, silu=True)
+    assert rel_l2(out.reshape(ns, rows, c1 + c2), ref) < 2e-3
+
+
+@pytest.mark.parametrize("c", [64, 320, 512, 1280])
+def test_layernorm(ops, c):
+    g = torch.Generator().manual_seed(c)
+    x = (torch.randn(1001, c, generator=g) * 1.5 + 0.3).half()
+    gm, bt = (1 + 0.2 * torch.randn(c, generator=g)).half(), (0.2 * torch.randn(c, generator=g)).half()
+    ref = F.layer_norm(x.float(), (c,), gm.float(), bt.float(), 1e-5)
+    out = ops.layernorm(dev(x), dev(gm), dev(bt))
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+    assert rel_l2(out, ref) < 1e-3
+
+
+# ---- PnP injection: bit-exact ---------------------------------------------------------------------------
+def _mask_pair(frames, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (2, frames, h, w), generator=g, dtype=torch.int32)
+    u8[:, :, : h // 2] = torch.where(torch.rand(2, frames, h // 2, w, generator=g) < 0.5, 255, 0).int()
+    soft = (u8.float() / 255).half()
+    hard = (u8 > 10)
+    return soft, hard
+
+
+@pytest.mark.parametrize("bg", [False, True])
+def test_pnp_tokens_spatial_bit_exact(ops, bg):
+    from oracle import pnp_ref
+    g = torch.Generator().manual_seed(21)
+    Fr, H, W, C, mh, mw = 3, 5, 7, 64, 10, 14
+    q = torch.randn(5 * Fr, H * W, C, generator=g).half()
+    k = torch.randn(5 * Fr, H * W, C, generator=g).half()
+    q[4 * Fr, 0, :4] = torch.tensor([float("inf"), -0.0, float("nan"), 65504.0]).half()  # blend != select
+    q[1 * Fr, 0, :4] = torch.tensor([-0.0, -0.0, 1.0, -65504.0]).half()
+    soft, hard = _mask_pair(Fr, mh, mw, 5)
+    rq, rk = pnp_ref.inject_qk_spatial(q, k, [hard[0], hard[1]], Fr, H, W, inject_background=bg)
+    dq, dk = dev(q), dev(k)
+    ops.pnp_blend_tokens(dq, dev(hard.half()), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=Fr * H * W * C,
+                         f_stride=H * W * C, p_stride=C, base_chunk0=bg)
+    assert torch.equal(bits(dq), bits(rq)) and torch.equal(bits(dk), bits(rk))
+
+
+@pytest.mark.parametrize("bg", [False, True])
+def test_pnp_tokens_temporal_layout_bit_exact(ops, bg):
+    """the reference's temporal layout [5*HW, F, C] through the stride parameters, soft float masks"""
+    from oracle import pnp_ref
+    g = torch.Generator().manual_seed(22)
+    Fr, H, W, C = 4, 3, 5, 128
+    q = torch.randn(5 * H * W, Fr, C, generator=g).half()
+    k = torch.randn(5 * H * W, Fr, C, generator=g).half()
+    soft, hard = _mask_pair(Fr, 6, 10, 6)
+    rq, rk = pnp_ref.inject_qk_temporal(q, k, [soft[0], soft[1]], H, W, inject_background=bg)
+    dq, dk = dev(q), dev(k)
+    ops.pnp_blend_tokens(dq, dev(soft), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=H * W * Fr * C,
+                         f_stride=C, p_stride=Fr * C, base_chunk0=bg)
+    assert torch.equal(bits(dq), bits(rq)) and torch.equal(bits(dk), bits(rk))
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (5, 7)])
+def test_pnp_nchw_bit_exact(ops, hw):
+    from oracle import pnp_ref
+    g = torch.Generator().manual_seed(23)
+    Fr, C = 3, 20
+    H, W = hw
+    x = torch.randn(5 * Fr, C, H, W, generator=g).half()
+    soft, hard = _mask_pair(Fr, H, W, 7)
+    ref = pnp_ref.inject_feature_nchw(x, [hard[0], hard[1]])
+    dx = dev(x)
+    ops.pnp_blend_nchw(dx, dev(hard.half()), frames=Fr, base_chunk0=True)
+    assert torch.equal(bits(dx), bits(ref))
+
+
+@pytest.mark.parametrize("kind", ["g1_spatial", "g2_temporal"])
+@pytest.mark.parametrize("bg", [0, 1])
+def test_pnp_against_reference_golden(ops, golden_dir, kind, bg):
+    """Q/K after injection as captured from the REFERENCE's processors (tools/gen_golden.py), bit for bit"""
+    g = np.load(os.path.join(golden_dir, f"{kind}_proc_bg{bg}.npz"))
+    Fr, H, W = int(g["frames"]), int(g["height"]), int(g["width"])
+    q, k = torch.from_numpy(g["q_off"][:, 0]), torch.from_numpy(g["k_off"][:, 0])  # pre-injection projections
+    C = q.shape[-1]
+    dq, dk = dev(q), dev(k)
+    if kind == "g1_spatial":
+        masks = torch.from_numpy(g["mask_bool"])[:, 0, 0].half()
+        ops.pnp_blend_tokens(dq, dev(masks), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=Fr * H * W * C,
+                             f_stride=H * W * C, p_stride=C, base_chunk0=bool(bg))
+    else:
+        masks = torch.from_numpy(g["mask_float"])[:, 0, 0]
+        ops.pnp_blend_tokens(dq, dev(masks), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=H * W * Fr * C,
+                             f_stride=C, p_stride=Fr * C, base_chunk0=bool(bg))
+    assert np.array_equal(dq.cpu().numpy().view(np.uint16), g["q_on"][:, 0].view(np.uint16))
+    assert np.array_equal(dk.cpu().numpy().view(np.uint16), g["k_on"][:, 0].view(np.uint16))
+
+
+# ---- loop glue: bit-exact ------------------------------------------------------------------------------
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("cfg", [False, True])
+def test_ddim_step_bit_exact(ops, inverse, cfg):
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 4, 5, 8, 8, generator=g).half()
+    vu, vc = torch.randn(1, 4, 5, 8, 8, generator=g).half(), torch.randn(1, 4, 5, 8, 8, generator=g).half()
+    ref_s = (sched_ref.DDIMInverseSchedulerRef if inverse else sched_ref.DDIMSchedulerRef)()
+    ref_s.set_timesteps(50)
+    s = (DDIMInverseScheduler if inverse else DDIMScheduler)()
+    s.set_timesteps(50, device="cuda")
+    assert torch.equal(s.timesteps.cpu(), ref_s.timesteps)
+    for t in (ref_s.timesteps[0], ref_s.timesteps[17], ref_s.timesteps[-1]):
+        v = loops_ref.cfg_combine(vu, vc, 9.0) if cfg else vc
+        ref = loops_ref.scheduler_step_5d(ref_s, v, t, x)
+        out = s.step_fused(dev(x), dev(vc), t, v_uncond=dev(vu) if cfg else None, guidance_scale=9.0)
+        assert torch.equal(bits(out), bits(ref)), int(t)
+
+
+@pytest.mark.parametrize("rnf", [False, True])
+@pytest.mark.parametrize("ratio", [0.0, 0.8, 0.01])
+def test_latent_fusion_bit_exact(ops, rnf, ratio):
+    from oracle import loops_ref
+    g = torch.Generator().manual_seed(32)
+    shp = (1, 4, 6, 9, 10)
+    lat, bgl = torch.randn(shp, generator=g).half(), torch.randn(shp, generator=g).half()
+    objs = torch.randn((2,) + shp, generator=g).half()
+    masks = (torch.randint(0, 256, (2,) + shp, generator=g).float() / 255).half()
+    ref = loops_ref.latent_fusion(lat, bgl, [objs[0], objs[1]], [masks[0], masks[1]], ratio, rnf)
+    out = ops.latent_fusion(dev(lat), dev(bgl), dev(objs), dev(masks), ratio, rnf)
+    assert torch.equal(bits(out), bits(ref))
+
+
+# ---- stem -------------------------------------------------------------------------------------------------
+def test_timestep_embedding(ops):
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([981.0, 1.0, 500.0, 8.0])
+    out = ops.timestep_embedding(t.cuda(), 320)
+    ref = timestep_embedding(t, 320)
+    assert (out.float().cpu() - ref).abs().max() < 2e-3
+
+
+def test_conv3x3_small_and_pool(ops):
+    from mvoc_amd.unet import pack_conv3x3_small
+    g = torch.Generator().manual_seed(41)
+    n, cin, cout, h, w = 3, 4, 32, 12, 10
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 6).half()
+    b = torch.randn(cout, generator=g).half()
+    for stride, silu in ((1, True), (2, False)):
+        ref = F.conv2d(x.float(), wt.float(), b.float(), stride=stride, padding=1)
+        ref = F.silu(ref) if silu else ref
+        out, ho, wo = ops.conv3x3_small(dev(_nhwc(x)), pack_conv3x3_small(dev(wt)), dev(b), nimg=n, h=h, wd=w, cin=cin, cout=cout,
+                                        stride=stride, silu=silu)
+        assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
+    ref = F.adaptive_avg_pool2d(x.float(), (8, 4))
+    out = ops.adaptive_avgpool(dev(_nhwc(x)), nimg=n, h=h, w=w, c=cin, oh=8, ow=4)
+    assert rel_l2(_from_rows(out, n, 8, 4), ref) < 1e-3
+
+
+def test_temporal_encoder4_and_layout(ops):
+    from oracle import unet_ref as U
+    torch.manual_seed(0)
+    enc = U.I2VGenXLTransformerTemporalEncoder(4, 2, 4, 16)
+    U.init_weights_(enc, seed=3, scale_out=False)
+    for p in enc.parameters():
+        p.copy_(p.half().float() * 3)
+    b, f, hw = 2, 5, 9
+    x = torch.randn(b, 4, f, hw, 1)
+    seq = x[..., 0].permute(0, 3, 2, 1).reshape(b * hw, f, 4)  # [b*hw, f, 4]
+    ref = enc(seq.half().float()).reshape(b, hw, f, 4).permute(0, 2, 1, 3)  # [b, f, hw, 4]
+    sd = {k: v.half().cuda() for k, v in enc.state_dict().items()}
+    blob = torch.cat([sd[k].reshape(-1) for k in ("norm1.weight", "norm1.bias", "attn1.to_q.weight", "attn1.to_k.weight",
+                                                  "attn1.to_v.weight", "attn1.to_out.0.weight", "attn1.to_out.0.bias",
+                                                  "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff.net.2.weight", "ff.net.2.bias")])
+    tok = torch.empty(b * f * hw, 4, dtype=torch.float16, device="cuda")
+    ops.ncfhw_to_tokens(dev(x), tok)
+    assert torch.equal(tok.cpu().reshape(b, f, hw, 4), x[..., 0].half().permute(0, 2, 3, 1))
+    out = torch.zeros(b * f * hw, 8, dtype=torch.float16, device="cuda")
+    ops.temporal_encoder4(tok, blob.contiguous(), out, b=b, f=f, hw=hw, coff=4)
+    assert rel_l2(out[:, 4:].reshape(b, f, hw, 4), ref) < 3e-3
+    back = ops.tokens_to_ncfhw(out[:, 4:].contiguous(), b, 4, f, hw, 1)
+    assert torch.equal(back.cpu()[..., 0].permute(0, 2, 3, 1), out[:, 4:].cpu().reshape(b, f, hw, 4))
