@@ -127,6 +127,16 @@ int fill_args(const mvoc_pnp_desc* d, PnpArgs& a) {
 }
 
 // ---- loop glue -----------------------------------------------------------------------------------
+// fp32-scalar x fp16-tensor products of the reference's eager chain (python float / 0-dim fp32 tensor times a
+// half tensor) are formed in fp32, ROUNDED TO fp32, then rounded to fp16 -- two roundings.  Left to itself hipcc
+// contracts `(half)(s * (float)h)` into v_fma_mixlo_f16, which rounds the exact 35-bit product once and differs
+// by 1 ulp at ~2^-9 of the elements (observed on MI355X).  The empty asm pins the fp32 product in a VGPR.
+__device__ __forceinline__ float smul16(float scalar, float x) {
+  float p = scalar * x;
+  asm volatile("" : "+v"(p));
+  return r16(p);
+}
+
 __global__ __launch_bounds__(256) void ddim_step_kernel(const half_t* __restrict__ x, const half_t* __restrict__ vu,
                                                         const half_t* __restrict__ vc, const float* __restrict__ coef,
                                                         half_t* __restrict__ out, long n) {
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const half_t* __restrict
   float v = (float)vc[i];
   if (vu) {
     const float u = (float)vu[i];
-    v = r16(u + r16(g * r16(v - u)));
+    v = r16(u + smul16(g, r16(v - u)));
   }
-  const float x0 = r16(r16(sa * xs) - r16(sb * v));
-  const float eps = r16(r16(sa * v) + r16(sb * xs));
-  const float dir = r16(sq * eps);
-  out[i] = (half_t)(r16(sp * x0) + dir);
+  const float x0 = r16(smul16(sa, xs) - smul16(sb, v));
+  const float eps = r16(smul16(sa, v) + smul16(sb, xs));
+  const float dir = smul16(sq, eps);
+  out[i] = (half_t)(smul16(sp, x0) + dir);
 }
 
 __global__ __launch_bounds__(256) void fusion_kernel(const half_t* __restrict__ lat, const half_t* __restrict__ bg,
@@ -151,13 +161,13 @@ __global__ __launch_bounds__(256) void fusion_kernel(const half_t* __restrict__ 
                                                      int rnf) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float l = r16(r16(mix * (float)lat[i]) + r16(omix * (float)bg[i]));
+  float l = r16(smul16(mix, (float)lat[i]) + smul16(omix, (float)bg[i]));
   for (int j = 0; j < nobj; ++j) {
     const float m = (float)masks[(long)j * n + i];
     const float inv_obj = r16((float)objs[(long)j * n + i] * m);
     const float background = r16(l * r16(1.0f - m));
     float fusion = inv_obj;
-    if (rnf) fusion = r16(r16(mix * r16(l * m)) + r16(omix * inv_obj));
+    if (rnf) fusion = r16(smul16(mix, r16(l * m)) + smul16(omix, inv_obj));
     l = r16(background + fusion);
   }
   out[i] = (half_t)l;
