@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""bench.py -- UNet3D denoising steps/sec of MVOC's hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], "boat_surf demo: background + 2 objects, 16x512x512, 50 DDIM steps, fp16"):
+the job is 3 DDIM inversions (background + 2 objects, UNet batch 1, cfg 1.0) and one PnP composition (UNet batch 5
+= [bg, obj1, obj2, uncond, cond], cfg 9.0, all five injection families on boat_surf's schedule), 50 steps each =
+200 UNet denoising steps.  One bench "step" is ONE UNet denoising step (UNet forward + injections + CFG + DDIM
+update + latent hand-off, all inputs resident in HBM); the K timed steps cycle through the job's mix
+[inversion, inversion, inversion, composition], so ``value`` = the job's average steps/s.  Synthetic latents /
+conditioning / seeded weights of the exact architecture (no checkpoint or dataset is reachable).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: the per-object inversions and per-entry compositions are independent (reference loops at
+inverse.py:136, composite.py:87), so every rank runs its own shard of steps with NO data-path collective;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks timing.  scaling = weak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP16_TFLOPS = 2500.0  # dense MFMA fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--latent", type=int, default=64, help="latent height = width (64 <-> 512x512 frames)")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class Job:
+    """the boat_surf job on synthetic data: an inversion stream (B=1) and a composition stream (B=5)"""
+
+    def __init__(self, device, frames, latent, use_graphs):
+        from mvoc_amd.pipeline import I2VGenXLPipeline
+        from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+        from mvoc_amd import pnp_utils
+        self.device = device
+        self.F, self.h = frames, latent
+        t0 = time.time()
+        self.pipe = I2VGenXLPipeline.synthetic(device=device, seed=8888, use_graphs=use_graphs)
+        torch.cuda.synchronize()
+        self.build_s = time.time() - t0
+        pipe, dev, F, h = self.pipe, device, frames, latent
+        H = W = latent * 8
+        g = torch.Generator().manual_seed(8888)
+        shape = (1, 4, F, h, h)
+        # ---- inversion stream (inverse.py: cfg 1.0, prompt "") ------------------------------------------------
+        self.inv_sched = DDIMInverseScheduler()
+        self.inv_sched.set_timesteps(50)
+        pipe.scheduler = self.inv_sched
+        pipe._guidance_scale = 1.0
+        self.inv_cond = pipe._stock_conditioning("", "", "first-frame", F, H, W, 8, None, None, None, None)
+        self.inv_latents = torch.randn(shape, generator=g).to(dev, torch.float16)
+        self.inv_state = pipe._make_stock_step("bench-inv", self.inv_latents, self.inv_cond, 1.0)
+        self.inv_table, self.inv_index = self.inv_sched.coef_table(dev, 1.0)
+        self.inv_i = 0
+        # ---- composition stream (composite.py on the boat_surf entry of group_composite/group_config.json) -----
+        self.sched = DDIMScheduler()
+        self.sched.set_timesteps(50)
+        ts = self.sched.timesteps
+        pnp_utils.modify_diffuser_attention_forward(pipe.unet)
+        pnp_utils.register_temp_attention_pnp(pipe, ts[:int(50 * 1.0)], False)
+        pnp_utils.register_spatial_attention_pnp(pipe, ts[:int(50 * 1.0)], False)
+        pnp_utils.register_temp_conv_injection(pipe, ts[:int(50 * 0.1)])
+        pnp_utils.register_out_conv_injection(pipe, ts[:int(50 * 0.1)])
+        pnp_utils.register_resnet_injection(pipe, ts[:int(50 * 0.1)])
+        gm = np.load(os.path.join(REPO, "tests", "golden", "g9_boat_surf_masks.npz"))
+        masks = []
+        for name in ("boat_mask", "surf_mask"):
+            u8 = torch.from_numpy(gm[f"{name}_64x64_float_u8"]).float()
+            if latent != 64 or frames != 16:
+                u8 = torch.nn.functional.interpolate(u8[None], size=(latent, latent), mode="nearest")[0]
+                u8 = u8[torch.arange(frames) % u8.shape[0]]
+            fl = (u8 / 255).to(torch.float16)[None, None].repeat(1, 4, 1, 1, 1).to(dev)
+            bl = (u8 > 10)[None, None].repeat(1, 4, 1, 1, 1).to(dev)
+            masks.append((fl, bl))
+        c = pipe.conditioner
+        pe, ne = c.encode_prompt("windsurf,sailboat,sky,ocean", "Chaotic, chaotic colors")
+        inv_pe, _ = c.encode_prompt("", "")
+        il = lambda k: c.image_latents(k, F, H, W)
+        emb = lambda k: torch.cat([c.encode_image(f"{k}-{i}") for i in range(F)], 1)
+        main_emb = emb("main")
+        cond = dict(
+            encoder_hidden_states=torch.cat([inv_pe.repeat(3, 1, 1), ne, pe]).contiguous(),
+            image_embeddings=torch.cat([emb("bg"), emb("obj1"), emb("obj2"), torch.zeros_like(main_emb), main_emb]).contiguous(),
+            image_latents_first=torch.cat([il("bg"), il("obj1"), il("obj2"), il("main"), il("main")]).contiguous(),
+            image_latents=torch.cat([il("bg"), il("obj1"), il("obj2"), il("main"), il("main")]).contiguous(),
+            fps=torch.full((5,), 8.0, dtype=torch.float32, device=dev))
+        pipe.scheduler = self.sched
+        pipe._guidance_scale = 9.0
+        self.comp_latents = torch.randn(shape, generator=g).to(dev, torch.float16)
+        self.comp_state = pipe.make_composition_state(self.comp_latents, cond, masks, 9.0)
+        self.comp_table, self.comp_index = self.sched.coef_table(dev, 9.0)
+        # inverted latents of the three sources at every timestep: resident in HBM (3 x 50 x 524 KB)
+        self.src = {(s, int(t)): torch.randn(shape, generator=g).to(dev, torch.float16) for s in range(3) for t in ts}
+        self.comp_i = 0
+
+    def inversion_step(self):
+        t = int(self.inv_sched.timesteps[self.inv_i % 50])
+        self.inv_i += 1
+        st = self.inv_state
+        st["t"].fill_(float(t))
+        st["coef"].copy_(self.inv_table[self.inv_index[t]])
+        st["run"]()
+        return st["latents"].clone()  # the per-step snapshot invert() appends / hands to the latent cache
+
+    def composition_step(self):
+        i = self.comp_i % 50
+        self.comp_i += 1
+        t = int(self.sched.timesteps[i])
+        bg, o1, o2 = self.src[(0, t)], self.src[(1, t)], self.src[(2, t)]
+        fuse = (0.0, False, [o1, o2]) if i < 1 else None  # fusion_step [0, 1], random_noise_ratio 0.0
+        self.pipe.composition_step(self.comp_state, t, bg, [o1, o2], self.comp_table[self.comp_index[t]], fuse)
+
+    def step(self, k):
+        if k % 4 == 3:
+            self.composition_step()
+        else:
+            self.inversion_step()
+
+
+def roofline_leg(job, steps):
+    """Repeat the timed steps eagerly with every launch bracketed by HIP events on the launch stream
+    (mvoc_prof_*).  A delay kernel is queued first so the host runs ahead and brackets see no launch gaps."""
+    from mvoc_amd import ops
+    from mvoc_amd.flops import unet_flops
+    pipe = job.pipe
+    saved = pipe.use_graphs
+    # eager twins of the captured iterations
+    inv_body = job.inv_state["run"].fn if hasattr(job.inv_state["run"], "fn") else job.inv_state["run"]
+    pipe.use_graphs = False
+    inv_run = job.inv_state["run"]
+    job.inv_state["run"] = inv_body
+    job.inv_i, job.comp_i = 0, 0
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for k in range(steps):
+        ops.delay_us(60000 if k % 4 != 3 else 20000)
+        job.step(k)
+    torch.cuda.synchronize()
+    ops.prof_enable(False)
+    fam = ops.prof_collect()
+    ops.prof_reset()
+    pipe.use_graphs = saved
+    job.inv_state["run"] = inv_run
+    cfg = pipe.unet.config
+    n_inv = sum(1 for k in range(steps) if k % 4 != 3)
+    n_comp = steps - n_inv
+    alg = n_inv * unet_flops(cfg, 1, job.F, job.h, job.h)["total"] + n_comp * unet_flops(cfg, 5, job.F, job.h, job.h)["total"]
+    g = fam["gemm"]
+    achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    total_ms = sum(v["ms"] for v in fam.values())
+    return {
+        "bound": "mfma", "kernel": "gemm_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
+        "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
+        "traffic": None,
+        "launches": int(g["launches"]), "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2),
+        "flops_per_launch_avg": g["work"] / max(g["launches"], 1),
+        "share_of_gpu_time": round(g["ms"] / total_ms, 4) if total_ms else None,
+        "algorithmic_tflop_all_steps": round(alg / 1e12, 2),
+        "by_family_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
+        "by_family_launches": {k: int(v["launches"]) for k, v in fam.items()},
+        "flash_attn_tflops": round(fam["flash_attn"]["work"] / max(fam["flash_attn"]["ms"], 1e-9) / 1e9, 2),
+        "temporal_attn_gbps": round(fam["temporal_attn"]["work"] / max(fam["temporal_attn"]["ms"], 1e-9) / 1e6, 1),
+        "groupnorm_gbps": round(fam["groupnorm"]["work"] / max(fam["groupnorm"]["ms"], 1e-9) / 1e6, 1),
+        "pnp_gbps": round(fam["pnp"]["work"] / max(fam["pnp"]["ms"], 1e-9) / 1e6, 1),
+        "note": "HIP events around every launch of an eager repeat of the timed steps; achieved = sum(2*m*n*k) / sum(duration)",
+    }
+
+
+def cpu_baseline(frames, latent):
+    """the oracle (CPU restatement, fp32, PyTorch CPU ops) on a bounded sample, scaled to the bench step by FLOPs"""
+    from oracle import unet_ref as U
+    from mvoc_amd.flops import unet_flops
+    from mvoc_amd.unet_spec import UNetConfig
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sample_hw = 16
+    cfg = UNetConfig()
+    with torch.device("meta"):
+        model = U.I2VGenXLUNet(U.UNetConfig())
+    model = model.to_empty(device="cpu")
+    with torch.no_grad():
+        noise = torch.randn(1 << 22) * 0.02  # cheap init (values are irrelevant to the timing, but must be finite/normal)
+        for p in model.parameters():
+            n = p.numel()
+            p.view(-1).copy_(noise.repeat((n + noise.numel() - 1) // noise.numel())[:n])
+        b, f = 1, frames
+        x = torch.randn(b, 4, f, sample_hw, sample_hw)
+        il = torch.randn(b, 4, f, sample_hw, sample_hw)
+        ie = torch.randn(b, 1, 1024)
+        eh = torch.randn(b, 77, 1024)
+        fps = torch.tensor([8])
+        t0 = time.time()
+        model(x, 981, fps, il, ie, eh)
+        dt = time.time() - t0
+    fl_sample = unet_flops(cfg, 1, frames, sample_hw, sample_hw)["total"]
+    fl_step = (3 * unet_flops(cfg, 1, frames, latent, latent)["total"] + unet_flops(cfg, 5, frames, latent, latent)["total"]) / 4
+    return {
+        "value": round((1.0 / dt) * fl_sample / fl_step, 6), "unit": "steps/s", "cores": cores, "kind": "port",
+        "sample": f"1 oracle UNet step (oracle/unet_ref.py, fp32 PyTorch CPU ops) at B=1, F={frames}, {sample_hw}x{sample_hw} latents "
+                  f"= {fl_sample / 1e12:.2f} TFLOP in {dt:.1f} s; scaled by FLOPs to the job-mix step ({fl_step / 1e12:.2f} TFLOP)",
+        "sample_seconds": round(dt, 2),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max-reduce only
+
+    job = Job(device, args.frames, args.latent, not args.no_graphs)
+    # prime every graph variant the timed region will replay, then W untimed warm-up steps
+    for k in range(4):
+        job.step(k)
+    job.comp_i = 5  # the (no feature injection) variant used from composition step 5 on
+    job.composition_step()
+    job.comp_i = 0
+    for k in range(args.warmup):
+        job.step(k)
+    job.inv_i, job.comp_i = 0, 0
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        job.step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kind timing (informational), same graphs
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - a) / n * 1e3
+
+    inv_ms = timed(job.inversion_step, 3)
+    comp_ms = timed(job.composition_step, 2)
+
+    out = None
+    if rank == 0:
+        from mvoc_amd.flops import unet_flops
+        cfg = job.pipe.unet.config
+        f1 = unet_flops(cfg, 1, args.frames, args.latent, args.latent)["total"]
+        f5 = unet_flops(cfg, 5, args.frames, args.latent, args.latent)["total"]
+        out = {
+            "metric": "UNet3D denoising steps/sec, 16x512^2 frames, inversion+compose",
+            "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {
+                "workload": f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "
+                            f"(UNet batch 5 = bg+2 objects+uncond+cond, cfg 9.0, all 5 injection families), "
+                            f"{args.frames} frames x {args.latent * 8}x{args.latent * 8}, 50-step DDIM schedules, fp16",
+                "frames": args.frames, "height": args.latent * 8, "width": args.latent * 8,
+                "unet_params": "1.42 B (I2VGen-XL architecture, seeded synthetic weights)",
+                "parallelism": "independent shards per GPU (no collectives)" if world > 1 else "single GPU",
+                "hip_graphs": not args.no_graphs,
+                "inversion_step_ms": round(inv_ms, 3), "composition_step_ms": round(comp_ms, 3),
+                "tflop_per_inversion_step": round(f1 / 1e12, 2), "tflop_per_composition_step": round(f5 / 1e12, 2),
+                "end_to_end_tflops": round((3 * f1 + f5) / 4 * args.steps / dt / 1e12 * (1 if world == 1 else 1), 2),
+            },
+        }
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline_leg(job, args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.frames, args.latent)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -190,6 +190,8 @@ enum { MVOC_FAM_GEMM = 0, MVOC_FAM_FLASH = 1, MVOC_FAM_TATTN = 2, MVOC_FAM_GN = 
 int mvoc_prof_enable(int on);                  /* 1: bracket every launch with hipEvents (not capture-safe) */
 int mvoc_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_or_bytes_per_family);
 int mvoc_prof_reset(void);
+/* enqueue a kernel that busy-waits `us` microseconds (lets the host run ahead so event brackets see no launch gaps) */
+int mvoc_delay_us(int64_t us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mvoc_prof_enable": (i32, [i32]),
     "mvoc_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "mvoc_prof_reset": (i32, []),
+    "mvoc_delay_us": (i32, [i64, vp]),
 }
 
 

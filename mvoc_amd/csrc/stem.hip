@@ -131,7 +131,7 @@ __global__ void temporal_encoder4_kernel(const half_t* __restrict__ x, const Enc
   if (idx >= total) return;
   const int p = (int)(idx % hw);
   const long bf = idx / hw;
-  const int fi = (int)(bf % f), bi = (int)(bf / f);
+  const int bi = (int)(bf / f);
   const half_t* xi = x + idx * 4;
   float yi[4], q[8];
   enc4_ln(xi, P, yi);
@@ -199,6 +199,13 @@ __global__ void temporal_encoder4_kernel(const half_t* __restrict__ x, const Enc
     for (int o = 0; o < 16; ++o) s += ff[o] * (float)P.w2[c * 16 + o];
     out[idx * ldo + coff + c] = (half_t)(r16(s + (float)P.b2[c]) + h1[c]);
   }
+}
+
+// busy-wait for `us` microseconds (s_memrealtime ticks at 100 MHz): lets the host run ahead of the GPU so that
+// per-launch HIP-event brackets measure kernels, not launch gaps
+__global__ void delay_kernel(long ticks) {
+  const long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
 inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
@@ -281,4 +288,10 @@ extern "C" int mvoc_temporal_encoder4_f16(const void* x, const void* params, voi
   hipLaunchKernelGGL(temporal_encoder4_kernel, dim3(nblk((long)b * f * hw)), dim3(256), 0, s, (const half_t*)x,
                      (const Enc4Params*)params, (half_t*)out, b, f, hw, ldo, coff);
   return mvoc_check_launch("temporal_encoder4_kernel");
+}
+
+extern "C" int mvoc_delay_us(int64_t us, void* stream) {
+  MVOC_REQUIRE(us >= 0 && us <= 2000000, -1, "delay_us: out of range");
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)us * 100);
+  return mvoc_check_launch("delay_kernel");
 }

@@ -325,3 +325,7 @@ def prof_collect():
     work = (C.c_double * n)()
     check(lib.mvoc_prof_collect(ms, cnt, work), "prof_collect")
     return {fam: {"ms": ms[i], "launches": cnt[i], "work": work[i]} for i, fam in enumerate(_ffi.FAMILIES)}
+
+
+def delay_us(us):
+    check(lib.mvoc_delay_us(int(us), _stream()), "delay_us")

@@ -1,0 +1,391 @@
+"""MVOC's three denoising loops on the MI355X engine, behind the reference pipeline's method names.
+
+Reference (``i2vgen-xl/pipelines/pipeline_i2vgen_xl.py``):
+  * ``I2VGenXLPipeline.invert``                       ``:1752-2018``  (loop body ``:1940-2000``)
+  * ``I2VGenXLPipeline.__call__``                     ``:980-1216``   (loop body ``:1167-1202``)
+  * ``I2VGenXLPipeline.sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection``
+                                                      ``:1220-1748``  (loop body ``:1636-1734``)
+
+Scope: the per-step work -- UNet forward, PnP injections, latent fusion, CFG, DDIM update,
+latent cache hand-off.  The once-per-clip encoders either side of the loops (CLIP text/vision, VAE) are "next"
+rows: they enter through a ``conditioner`` object (``encode_prompt / encode_image / image_latents /
+encode_video / decode``); ``SyntheticConditioner`` supplies tensors of the right shapes where no checkpoint
+exists.  Everything inside a loop iteration runs on the GPU through libmvoc_hip; with ``use_graphs`` the whole
+iteration is one captured hipGraph replay (~2000 kernel launches otherwise).
+"""
+import hashlib
+import logging
+import os
+from copy import deepcopy
+
+import torch
+
+from . import ops
+from .latent_cache import LatentCache
+from .pnp_utils import register_time_all
+from .schedulers import DDIMScheduler
+
+logger = logging.getLogger(__name__)
+H16 = torch.float16
+
+
+class PipelineOutput:
+    def __init__(self, frames=None, inverted_latents=None):
+        self.frames = frames
+        self.inverted_latents = inverted_latents
+
+
+class SyntheticConditioner:
+    """Deterministic stand-in for CLIP text/vision + VAE (SURVEY section 8d synthetic inputs): embeddings are
+    N(0,1) draws seeded by a hash of the prompt / image bytes; image latents are frame 0 = 0.18215*N(0,1)
+    followed by the frame-position ramp k/(F-1) exactly as ``prepare_image_latents`` (``:860-890``) builds it."""
+
+    cross_attention_dim = 1024
+    vae_scale_factor = 8
+
+    def __init__(self, device, cross_attention_dim=1024):
+        self.device = torch.device(device)
+        self.cross_attention_dim = cross_attention_dim
+
+    def _gen(self, *keys):
+        h = hashlib.sha256("|".join(str(k) for k in keys).encode()).digest()
+        return torch.Generator().manual_seed(int.from_bytes(h[:7], "little"))
+
+    @staticmethod
+    def _image_key(image):
+        if image is None:
+            return "none"
+        if hasattr(image, "tobytes"):
+            return hashlib.sha256(image.tobytes()).hexdigest()
+        return str(image)
+
+    def encode_prompt(self, prompt, negative_prompt=None):
+        pe = torch.randn(1, 77, self.cross_attention_dim, generator=self._gen("p", prompt)).to(self.device, H16)
+        ne = torch.randn(1, 77, self.cross_attention_dim, generator=self._gen("p", negative_prompt or "")).to(self.device, H16)
+        return pe, ne
+
+    def encode_image(self, image):
+        return torch.randn(1, 1, self.cross_attention_dim, generator=self._gen("i", self._image_key(image))).to(self.device, H16)
+
+    def image_latents(self, image, num_frames, height, width):
+        h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        first = 0.18215 * torch.randn(1, 4, 1, h, w, generator=self._gen("l", self._image_key(image), h, w))
+        if num_frames > 1:
+            ramp = torch.cat([torch.full((1, 4, 1, h, w), (k + 1) / (num_frames - 1)) for k in range(num_frames - 1)], 2)
+            first = torch.cat([first, ramp], 2)
+        return first.to(self.device, H16)
+
+    def encode_video(self, frames, height, width):
+        h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        lat = [0.18215 * 4 * torch.randn(4, h, w, generator=self._gen("v", self._image_key(f), h, w)) for f in frames]
+        return torch.stack(lat, 1)[None].to(self.device, H16)
+
+    def decode(self, latents):
+        raise NotImplementedError("VAE decode is a 'next' row (SURVEY 8f-1): pass output_type='latent'")
+
+
+class GraphedStep:
+    """Capture one loop iteration (a python callable working on static device buffers) into a hipGraph."""
+
+    def __init__(self, fn, warmup=2, preserve=()):
+        """``preserve``: tensors the iteration updates in place; they are restored after the eager warm-up runs"""
+        self.fn = fn
+        saved = [t.clone() for t in preserve]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+        for t, s in zip(preserve, saved):
+            t.copy_(s)
+
+    def __call__(self):
+        self.graph.replay()
+
+
+class I2VGenXLPipeline:
+    """Drop-in surface of the reference pipeline for the denoising path."""
+
+    def __init__(self, unet, scheduler=None, conditioner=None, use_graphs=True):
+        self.unet = unet
+        self.scheduler = scheduler or DDIMScheduler()
+        self.conditioner = conditioner or SyntheticConditioner(unet.device, unet.config.cross_attention_dim)
+        self.use_graphs = use_graphs
+        self.vae_scale_factor = 8
+        self._guidance_scale = 1.0
+        self._graphs = {}
+        self.latent_cache = LatentCache(unet.device)
+
+    # ---- reference plumbing ------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=H16, variant="fp16", device="cuda:0", **kw):
+        """Loads ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` (diffusers layout).  The text / image
+        encoders and the VAE of the checkpoint are outside this path's scope (see module docstring)."""
+        from safetensors.torch import load_file
+        from .unet import I2VGenXLUNet
+        for name in (f"diffusion_pytorch_model.{variant}.safetensors", "diffusion_pytorch_model.safetensors"):
+            f = os.path.join(path, "unet", name)
+            if os.path.exists(f):
+                unet = I2VGenXLUNet(device=device).load_state_dict(load_file(f))
+                return cls(unet, **kw)
+        raise FileNotFoundError(f"no UNet weights under {path}/unet (expected diffusers safetensors); for synthetic "
+                                "weights use mvoc_amd.pipeline.I2VGenXLPipeline.synthetic()")
+
+    @classmethod
+    def synthetic(cls, config=None, device="cuda:0", seed=8888, **kw):
+        from .unet import I2VGenXLUNet
+        return cls(I2VGenXLUNet(config, device=device).init_random(seed), **kw)
+
+    def to(self, device):
+        return self
+
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    def encode_vae_video(self, video, device=None, height=576, width=1024):
+        return self.conditioner.encode_video(video, height, width)
+
+    def prepare_latents(self, batch, channels, num_frames, height, width, dtype, device, generator, latents=None):
+        shape = (batch, channels, num_frames, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            g = generator if isinstance(generator, torch.Generator) and generator.device.type == "cpu" else None
+            latents = torch.randn(shape, generator=g, dtype=torch.float32).to(dtype)
+        return (latents.to(device, dtype) * self.scheduler.init_noise_sigma).contiguous()
+
+    # ---- conditioning ---------------------------------------------------------------------------------
+    def _stock_conditioning(self, prompt, negative_prompt, image, num_frames, height, width, target_fps, prompt_embeds,
+                            negative_prompt_embeds, image_embeddings, image_latents):
+        c = self.conditioner
+        if prompt_embeds is None:
+            prompt_embeds, negative_prompt_embeds = c.encode_prompt(prompt, negative_prompt)
+        if image_embeddings is None:
+            image_embeddings = c.encode_image(image)
+        if image_latents is None:
+            image_latents = c.image_latents(image, num_frames, height, width)
+        if self.do_classifier_free_guidance:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+            image_embeddings = torch.cat([torch.zeros_like(image_embeddings), image_embeddings])  # :766
+            image_latents = torch.cat([image_latents] * 2)
+        nb = prompt_embeds.shape[0]
+        fps = torch.full((nb,), float(target_fps), dtype=torch.float32, device=self.device)
+        return dict(encoder_hidden_states=prompt_embeds.to(self.device, H16).contiguous(),
+                    image_embeddings=image_embeddings.to(self.device, H16).contiguous(),
+                    image_latents=image_latents.to(self.device, H16).contiguous(), fps=fps)
+
+    # ---- one loop iteration each (static buffers so that they can be graph-captured) -------------------
+    def _make_stock_step(self, key, latents, cond, guidance_scale):
+        """iteration of invert / __call__: [cat x2] -> UNet -> CFG + (inverse-)DDIM update, in place on `state`"""
+        st = {"latents": latents.clone(), "t": torch.zeros(1, dtype=torch.float32, device=self.device),
+              "coef": torch.zeros(5, dtype=torch.float32, device=self.device)}
+        do_cfg = guidance_scale > 1
+
+        def body():
+            x = st["latents"]
+            inp = torch.cat([x, x]) if do_cfg else x
+            noise = self.unet.forward(inp, st["t"], cond["fps"], image_latents=cond["image_latents"],
+                                      image_embeddings=cond["image_embeddings"],
+                                      encoder_hidden_states=cond["encoder_hidden_states"])[0]
+            if do_cfg:
+                ops.ddim_step(x, noise[1:2].contiguous(), st["coef"], v_uncond=noise[0:1].contiguous(), out=x)
+            else:
+                ops.ddim_step(x, noise, st["coef"], out=x)
+
+        st["run"] = GraphedStep(body, preserve=(st["latents"],)) if self.use_graphs else body
+        return st
+
+    def _run_stock_loop(self, latents, cond, num_inference_steps, guidance_scale, first_idx=0, on_step=None):
+        sched = self.scheduler
+        sched.set_timesteps(num_inference_steps, device=self.device)
+        sched.timesteps = sched.timesteps[first_idx:]
+        table, index = sched.coef_table(self.device, guidance_scale)
+        key = ("stock", tuple(latents.shape), guidance_scale > 1, type(sched).__name__,
+               tuple(t.data_ptr() for t in cond.values()))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = self._make_stock_step(key, latents, cond, guidance_scale)
+        st["latents"].copy_(latents)
+        for i, t in enumerate(sched.timesteps):
+            st["t"].fill_(float(t))
+            st["coef"].copy_(table[index[int(t)]])
+            st["run"]()
+            if on_step is not None:
+                on_step(i, int(t), st["latents"])
+        return st["latents"].clone()
+
+    # ---- reference methods -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def invert(self, prompt=None, image=None, height=704, width=1280, target_fps=16, num_frames=16,
+               num_inference_steps=50, guidance_scale=9.0, negative_prompt=None, eta=0.0, num_videos_per_prompt=1,
+               decode_chunk_size=1, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+               output_type="pil", return_dict=True, cross_attention_kwargs=None, clip_skip=1, output_dir=None,
+               image_embeddings=None, image_latents=None):
+        """DDIM inversion; writes ``ddim_latents_{t}.pt`` per step and returns ``[1, steps, 4, F, h, w]`` noisiest first."""
+        self._guidance_scale = guidance_scale
+        cond = self._stock_conditioning(prompt, negative_prompt, image, num_frames, height, width, target_fps, prompt_embeds,
+                                        negative_prompt_embeds, image_embeddings, image_latents)
+        latents = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, generator, latents)
+        seq = []
+
+        def on_step(i, t, lat):
+            snap = lat.clone()
+            seq.append(snap)
+            self.latent_cache.put(output_dir, t, snap)  # device-resident hand-off + async torch.save
+
+        self._run_stock_loop(latents, cond, num_inference_steps, guidance_scale, on_step=on_step)
+        self.latent_cache.flush()
+        inverted = torch.stack(list(reversed(seq)), 1)
+        if not return_dict:
+            return inverted
+        return PipelineOutput(inverted_latents=inverted)
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, height=704, width=1280, target_fps=16, num_frames=16,
+                 num_inference_steps=50, guidance_scale=9.0, negative_prompt=None, eta=0.0, num_videos_per_prompt=1,
+                 decode_chunk_size=1, generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                 output_type="pil", return_dict=True, cross_attention_kwargs=None, clip_skip=1, ddim_init_latents_t_idx=0,
+                 image_embeddings=None, image_latents=None):
+        self._guidance_scale = guidance_scale
+        cond = self._stock_conditioning(prompt, negative_prompt, image, num_frames, height, width, target_fps, prompt_embeds,
+                                        negative_prompt_embeds, image_embeddings, image_latents)
+        latents = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, generator, latents)
+        latents = self._run_stock_loop(latents, cond, num_inference_steps, guidance_scale, first_idx=ddim_init_latents_t_idx)
+        frames = latents if output_type == "latent" else self.conditioner.decode(latents)
+        return PipelineOutput(frames=frames) if return_dict else (frames,)
+
+    # ---- composition --------------------------------------------------------------------------------------
+    def make_composition_state(self, latents, cond, masks, guidance_scale):
+        """static buffers + the captured iteration variants of the composition loop.
+        cond: dict(encoder_hidden_states [n,77,D], image_embeddings [n,F,D], image_latents_first, image_latents, fps)"""
+        n_obj = len(masks)
+        nb = n_obj + 3
+        dev = self.device
+        st = {"latents": latents.clone(), "inp": torch.empty((nb,) + tuple(latents.shape[1:]), dtype=H16, device=dev),
+              "t": torch.zeros(1, dtype=torch.float32, device=dev), "coef": torch.zeros(5, dtype=torch.float32, device=dev),
+              "masks": masks, "variants": {}, "cond": cond, "n_obj": n_obj,
+              "fusion_masks": torch.stack([m[0].to(dev, H16) for m in masks]).contiguous(),
+              "fusion_objs": torch.empty((n_obj,) + tuple(latents.shape), dtype=H16, device=dev)}
+
+        def body():
+            x = st["latents"]
+            st["inp"][nb - 2].copy_(x[0])
+            st["inp"][nb - 1].copy_(x[0])
+            noise = self.unet.forward_ext(st["inp"], st["t"], cond["fps"], cond["image_latents_first"], cond["image_latents"],
+                                          cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False)[0]
+            ops.ddim_step(x, noise[nb - 1:nb].contiguous(), st["coef"], v_uncond=noise[nb - 2:nb - 1].contiguous(), out=x)
+
+        st["body"] = body
+        return st
+
+    def composition_step(self, st, t, bg_latents, obj_latents, table_row, fuse=None):
+        """one iteration of ``:1636-1734`` on device-resident latents; ``fuse`` = (mix_ratio, obj_random_noise_fusion,
+        fusion object latents) on fusion steps"""
+        nb = st["n_obj"] + 3
+        if fuse is not None:
+            mix, rnf, fobjs = fuse
+            for j, o in enumerate(fobjs):
+                st["fusion_objs"][j].copy_(o)
+            ops.latent_fusion(st["latents"], bg_latents, st["fusion_objs"], st["fusion_masks"], mix, rnf, out=st["latents"])
+            obj_latents = fobjs
+        st["inp"][0].copy_(bg_latents[0])
+        for j, o in enumerate(obj_latents):
+            st["inp"][1 + j].copy_(o[0])
+        st["t"].fill_(float(t))
+        st["coef"].copy_(table_row)
+        register_time_all(self, int(t), st["masks"])
+        u = self.unet
+        flags = (u.conv_out.injecting(), u.up_blocks[-1].attentions[0].transformer_blocks[0].attn1.processor.injecting(),
+                 u.up_blocks[-1].temp_attentions[0].transformer_blocks[0].attn1.processor.injecting())
+        if not self.use_graphs:
+            st["body"]()
+            return
+        g = st["variants"].get(flags)
+        if g is None:
+            g = st["variants"][flags] = GraphedStep(st["body"], preserve=(st["latents"],))
+        g()
+
+    @torch.no_grad()
+    def sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection(
+            self, prompt=None, main_first_image=None, main_image_list=None, background_first_image=None,
+            background_image_list=None, objs_first_image=None, objs_image_list=None, height=704, width=1280, target_fps=16,
+            num_frames=16, num_inference_steps=50, guidance_scale=9.0, negative_prompt=None, eta=0.0,
+            num_videos_per_prompt=1, decode_chunk_size=1, generator=None, latents=None, prompt_embeds=None,
+            negative_prompt_embeds=None, output_type="pil", return_dict=True, cross_attention_kwargs=None, clip_skip=1,
+            fusion_steps=(0, 3), ddim_init_latents_t_idx=1, ddim_inv_prompt=None, obj_mask=None, obj_width_height=None,
+            obj_ddim_latents_idx_offset=None, obj_random_noise_fusion=False, random_noise_ratio=0.0,
+            bg_inv_latents_path=None, obj_ddim_latents_path=None, obj_masks_tensors=None):
+        """PnP composition sampling.  ``obj_mask``: list of mask paths (preprocessed by ``mvoc_amd.utils.mask_preprocess``)
+        or pass ``obj_masks_tensors`` = list of (float [1,4,F,h,w], bool [1,4,F,h,w]) directly."""
+        from .utils import mask_preprocess
+        self._guidance_scale = guidance_scale
+        if guidance_scale <= 1:
+            raise NotImplementedError("the reference's hooks hard-code the CFG batch layout [bg, objs.., uncond, cond]")
+        c = self.conditioner
+        n_obj = len(obj_ddim_latents_path)
+        assert obj_mask is None or len(obj_mask) == n_obj
+        # conditioning, assembled in the reference's batch order [bg, obj_1.., uncond, cond] (:1387, 1476, 1498, 1540)
+        pe, ne = (prompt_embeds, negative_prompt_embeds) if prompt_embeds is not None else c.encode_prompt(prompt, negative_prompt)
+        inv_pe, _ = c.encode_prompt(ddim_inv_prompt, negative_prompt)
+        ehs = torch.cat([inv_pe.repeat(n_obj + 1, 1, 1), ne, pe])
+        main_lat = c.image_latents(main_first_image, num_frames, height, width)
+        bg_lat = c.image_latents(background_first_image, num_frames, height, width)
+        obj_first = [c.image_latents(im, num_frames, height, width) for im in objs_first_image]
+        first_all = torch.cat([bg_lat] + obj_first + [main_lat, main_lat])
+        obj_lat = [c.image_latents(frames[0], num_frames, height, width) for frames in objs_image_list]
+        bg_lat2 = c.image_latents(background_image_list[0], num_frames, height, width)
+        lat_all = torch.cat([bg_lat2] + obj_lat + [main_lat, main_lat])
+
+        def emb_list(frames):
+            return torch.cat([c.encode_image(f) for f in frames], dim=1)
+
+        main_emb = emb_list(main_image_list)
+        emb_all = torch.cat([emb_list(background_image_list)] + [emb_list(fr) for fr in objs_image_list]
+                            + [torch.zeros_like(main_emb), main_emb])
+        fps = torch.full((n_obj + 3,), float(target_fps), dtype=torch.float32, device=self.device)
+        cond = dict(encoder_hidden_states=ehs.to(self.device, H16).contiguous(), image_embeddings=emb_all.to(self.device, H16).contiguous(),
+                    image_latents_first=first_all.to(self.device, H16).contiguous(), image_latents=lat_all.to(self.device, H16).contiguous(), fps=fps)
+
+        sched = self.scheduler
+        sched.set_timesteps(num_inference_steps, device=self.device)
+        full = deepcopy(sched)
+        sched.timesteps = sched.timesteps[ddim_init_latents_t_idx:]
+        offs = obj_ddim_latents_idx_offset or [0] * n_obj
+        fusion_ts = [[int(full.timesteps[offs[j]:][k]) for k in range(*fusion_steps)] for j in range(n_obj)]
+        latents = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, generator, latents)
+        if obj_masks_tensors is None:
+            obj_masks_tensors = [mask_preprocess(m, self.device, H16, 1, 4, num_frames, downscale=8) for m in obj_mask]
+        st = self.make_composition_state(latents, cond, obj_masks_tensors, guidance_scale)
+        table, index = sched.coef_table(self.device, guidance_scale)
+        cache = self.latent_cache
+        fusion_counter = 0  # never incremented in the reference (:1634, 1649)
+        for i, t in enumerate(sched.timesteps):
+            t = int(t)
+            bg = cache.get(bg_inv_latents_path, t)
+            fuse = None
+            if fusion_steps[0] <= i < fusion_steps[1]:
+                fobjs = [cache.get(obj_ddim_latents_path[j], fusion_ts[j][fusion_counter]) for j in range(n_obj)]
+                fuse = (random_noise_ratio, obj_random_noise_fusion, fobjs)
+                objs = fobjs
+            else:
+                objs = [cache.get(obj_ddim_latents_path[j], t) for j in range(n_obj)]
+            self.composition_step(st, t, bg, objs, table[index[t]], fuse)
+        latents = st["latents"].clone()
+        frames = latents if output_type == "latent" else c.decode(latents)
+        return PipelineOutput(frames=frames) if return_dict else (frames,)
