@@ -110,8 +110,13 @@ class Job:
         # inverted latents of the three sources at every timestep: resident in HBM (3 x 50 x 524 KB)
         self.src = {(s, int(t)): torch.randn(shape, generator=g).to(dev, torch.float16) for s in range(3) for t in ts}
         self.comp_i = 0
+        self._hooks_live = False
 
     def inversion_step(self):
+        if self._hooks_live:  # the two stages share one engine here: clear the composition's hook state
+            from mvoc_amd import pnp_utils
+            pnp_utils.register_time_all(self.pipe, None, None)
+            self._hooks_live = False
         t = int(self.inv_sched.timesteps[self.inv_i % 50])
         self.inv_i += 1
         st = self.inv_state
@@ -126,6 +131,7 @@ class Job:
         t = int(self.sched.timesteps[i])
         bg, o1, o2 = self.src[(0, t)], self.src[(1, t)], self.src[(2, t)]
         fuse = (0.0, False, [o1, o2]) if i < 1 else None  # fusion_step [0, 1], random_noise_ratio 0.0
+        self._hooks_live = True
         self.pipe.composition_step(self.comp_state, t, bg, [o1, o2], self.comp_table[self.comp_index[t]], fuse)
 
     def step(self, k):
@@ -189,7 +195,9 @@ def cpu_baseline(frames, latent):
     from oracle import unet_ref as U
     from mvoc_amd.flops import unet_flops
     from mvoc_amd.unet_spec import UNetConfig
-    cores = os.cpu_count() or 1
+    # PyTorch CPU ops stop scaling (and regress badly) far below the 256 hardware threads of the GPU host on these
+    # op sizes: 32 threads is what is used and what `cores` reports
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sample_hw = 16
     cfg = UNetConfig()

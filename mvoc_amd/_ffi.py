@@ -6,6 +6,11 @@ PyTorch fallback behind any op in this package.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so; it must be the HIP runtime of the process.  Importing torch first
+# makes our DT_NEEDED libamdhip64.so.7 resolve to the already-loaded copy -- loading /opt/rocm's copy first would
+# put two HIP runtimes in one process (our launches then fail with "no ROCm-capable device is detected").
+import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvoc_hip.so")
 
@@ -95,6 +100,12 @@ def _load():
 lib = _load()
 
 
+_DEBUG_SYNC = bool(os.environ.get("MVOC_DEBUG_SYNC"))
+
+
 def check(rc, what=""):
     if rc != 0:
         raise RuntimeError(f"libmvoc_hip {what} failed ({rc}): {lib.mvoc_last_error().decode()}")
+    if _DEBUG_SYNC:  # debugging aid: localise an asynchronous fault to the op that caused it
+        print(f"[mvoc] {what}", flush=True)
+        torch.cuda.synchronize()

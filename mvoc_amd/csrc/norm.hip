@@ -78,22 +78,40 @@ __global__ __launch_bounds__(256) void gn_partial(const GnArgs p) {
   }
 }
 
-__global__ void gn_final(const GnArgs p) {
-  const int g = threadIdx.x, smp = blockIdx.x;
-  if (g >= p.G) return;
+// Chan-combine the slab partials of one sample.  256 threads: lane = tid / G walks a strided subset of the slabs
+// for group g = tid % G (independent loads stay in flight), then lane 0 merges the per-lane results in fixed order.
+__global__ __launch_bounds__(256) void gn_final(const GnArgs p) {
+  __shared__ float ln[256], lmean[256], lm2[256];
+  const int tid = threadIdx.x, smp = blockIdx.x;
+  const int lanes = 256 / p.G;
+  const int g = tid % p.G, lane = tid / p.G;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int c = 0; c < p.nchunk; ++c) {
-    const float* in = p.ws + (((long)smp * p.nchunk + c) * p.G + g) * 3;
-    const float nb = in[0], mb = in[1], m2b = in[2];
-    if (nb <= 0.f) continue;
-    const float nt = n + nb, delta = mb - mean;
-    mean += delta * (nb / nt);
-    m2 += m2b + delta * delta * (n * nb / nt);
-    n = nt;
+  if (lane < lanes) {
+    for (int c = lane; c < p.nchunk; c += lanes) {
+      const float* in = p.ws + (((long)smp * p.nchunk + c) * p.G + g) * 3;
+      const float nb = in[0], mb = in[1], m2b = in[2];
+      if (nb <= 0.f) continue;
+      const float nt = n + nb, delta = mb - mean;
+      mean += delta * (nb / nt);
+      m2 += m2b + delta * delta * (n * nb / nt);
+      n = nt;
+    }
   }
-  float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + ((long)smp * p.G + g) * 2;
-  fin[0] = mean;
-  fin[1] = rsqrtf(m2 / n + p.eps);
+  ln[tid] = n; lmean[tid] = mean; lm2[tid] = m2;
+  __syncthreads();
+  if (lane == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const float nb = ln[l * p.G + g], mb = lmean[l * p.G + g], m2b = lm2[l * p.G + g];
+      if (nb <= 0.f) continue;
+      const float nt = n + nb, delta = mb - mean;
+      mean += delta * (nb / nt);
+      m2 += m2b + delta * delta * (n * nb / nt);
+      n = nt;
+    }
+    float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + ((long)smp * p.G + g) * 2;
+    fin[0] = mean;
+    fin[1] = rsqrtf(m2 / n + p.eps);
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
@@ -137,8 +155,9 @@ void gn_geometry(GnArgs& a) {
   a.CW = cchunks < 256 ? cchunks : 256;
   a.RY = 256 / a.CW;
   a.npass = (cchunks + a.CW - 1) / a.CW;
-  int want = 4096 / (a.nsample > 0 ? a.nsample : 1);
+  int want = 2048 / (a.nsample > 0 ? a.nsample : 1);
   if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
   int maxchunk = (a.R + a.RY * 4 - 1) / (a.RY * 4);  // at least 4 rows per thread-row
   if (maxchunk < 1) maxchunk = 1;
   a.nchunk = want < maxchunk ? want : maxchunk;

@@ -173,6 +173,7 @@ class Transformer2DModel(_TransformerBase):
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         proc = blk.attn1.processor
         if proc.injecting():
+            eng.check_pnp_batch(B, proc.mask)
             masks = eng.device_masks(proc.mask)[1]  # bool masks as {0,1} fp16
             ld = qkv.stride(0)
             ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
@@ -212,6 +213,7 @@ class TransformerTemporalModel(_TransformerBase):
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
             proc = attn.processor
             if attn is blk.attn1 and proc.injecting():
+                eng.check_pnp_batch(B, proc.mask)
                 masks = eng.device_masks(proc.mask)[0]  # soft float masks, channel 0
                 ld = qkv.stride(0)
                 ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
@@ -452,6 +454,14 @@ class I2VGenXLUNet:
         self._loaded = True
 
     # ---- PnP helpers ------------------------------------------------------------------------------
+    @staticmethod
+    def check_pnp_batch(B, mask_list):
+        """the hooks address chunks positionally [bg, obj_1..obj_n, uncond, cond] (pnp_utils.py:592 hard-codes 5)"""
+        if mask_list is None or B != len(mask_list) + 3:
+            raise RuntimeError(f"PnP injection is active but the UNet batch is {B}, expected n_objects+3 = "
+                               f"{None if mask_list is None else len(mask_list) + 3} ([bg, objects.., uncond, cond]); "
+                               "clear the hook state (register_time_all(pipe, None, None)) before non-composition calls")
+
     def device_masks(self, mask_list):
         """list of (float [1,4,F,h,w], bool [1,4,F,h,w]) pairs (``register_time_all``'s ``mask``) ->
         (soft fp16 [nobj,F,h,w] from channel 0, hard {0,1} fp16 [nobj,F,h,w]); cached per mask list object."""
@@ -465,6 +475,7 @@ class I2VGenXLUNet:
     def inject_features(self, h, mask_list, geo, channels):
         """feature injection (``pnp_utils.py:970-1004, 1059-1082, 1114-1146``): base = chunk 0, bool mask, no resize"""
         B, F, H, W = geo
+        self.check_pnp_batch(B, mask_list)
         hard = self.device_masks(mask_list)[1]
         if hard.shape[2] != H or hard.shape[3] != W:
             raise RuntimeError(f"feature injection needs masks at the feature resolution {(H, W)}, got "
@@ -496,9 +507,8 @@ class I2VGenXLUNet:
         cfg = self.config
         B = image_latents.shape[0]
         h, w = image_latents.shape[-2:]
-        frames = list(range(F)) if multi_frame_guidance else [0]
-        nf = len(frames)
-        lat = image_latents[:, :, frames].to(self.device, H16)  # [B,4,nf,h,w]
+        nf = F if multi_frame_guidance else 1
+        lat = image_latents[:, :, :nf].to(self.device, H16)  # [B,4,nf,h,w]  (slices only: graph-capture safe)
         tok = torch.empty((B * nf * h * w, 4), dtype=H16, device=self.device)
         ops.ncfhw_to_tokens(lat, tok)
         (w0, b0), (w1, b1), (w2, b2) = self.ctx_convs
@@ -511,7 +521,7 @@ class I2VGenXLUNet:
         ie = image_embeddings.to(self.device, H16)
         if ie.dim() == 2:
             ie = ie[:, None]
-        ie = ie[:, frames].reshape(B * nf, -1).contiguous()
+        ie = ie[:, :nf].reshape(B * nf, -1).contiguous()
         it = self.context_embedding[1](self.context_embedding[0](ie, act=ACT_SILU))  # [B*nf, 4*ctx]
         ntext = encoder_hidden_states.shape[1]
         L = ntext + nlat + cfg.in_channels
@@ -604,6 +614,7 @@ class I2VGenXLUNet:
         co = self.conv_out
         y, _, _ = ops.conv3x3(h, co.w, co.b, nimg=B * F, h=H, wd=W, n_store=co.cout)
         if co.injecting():
+            self.check_pnp_batch(B, co.mask)
             # conv_out writes cout (4) channels into a [rows, 4] buffer: the token kernel needs channels % 8 == 0,
             # so this tiny tensor goes through the NCHW form of the kernel on the boundary layout instead
             out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)  # [B,C,F,h,w]
