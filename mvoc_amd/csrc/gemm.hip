@@ -51,6 +51,85 @@ struct RowInfo {   // per staged activation row (fixed for the whole K loop)
 };
 
 template <int WN, int WM, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TN][TM], int n0, int m0, int wn, int wm,
+                                              int r, int h) {
+  // ---- epilogue: lane owns pixel m = tile_m + r and, per register quad q, channels n..n+3 ---------------
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + (wm * TM + j) * 32 + r;
+    if (m >= p.M) continue;
+    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd : nullptr;
+    const half_t* rs = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
+    half_t* orow = p.out + (size_t)m * p.ldo;
+    if (p.act == MVOC_ACT_GEGLU) {
+      if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; i += 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nh = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;  // packed row of the value half
+            if (nh >= p.N) continue;
+            const int no = (n0 + (wn * TN + i) * 32) / 2 + 8 * q + 4 * h;
+            half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+            if (p.bias) {
+              bh = *reinterpret_cast<const half4_t*>(p.bias + nh);
+              bg = *reinterpret_cast<const half4_t*>(p.bias + nh + 32);
+            }
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float hv = r16(acc[i][j][q * 4 + e] + (float)bh[e]);
+              const float gv = r16(acc[i + 1][j][q * 4 + e] + (float)bg[e]);
+              float v = r16(hv * r16(gelu_erf_f(gv)));
+              if (rs) v = r16(v + (float)rs[no + e]);
+              o[e] = (half_t)v;
+            }
+            *reinterpret_cast<half4_t*>(orow + no) = o;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+          if (n >= p.n_store) continue;
+          half4_t b4 = {0, 0, 0, 0};
+          if (p.bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
+          if (ra) {
+            const half4_t t4 = *reinterpret_cast<const half4_t*>(ra + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
+          }
+          if (p.act == MVOC_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+          } else if (p.act == MVOC_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(gelu_erf_f(v[e]));
+          }
+          if (rs) {
+            const half4_t r4 = *reinterpret_cast<const half4_t*>(rs + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)r4[e]);
+          }
+          if (n + 4 <= p.n_store) {
+            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(orow + n) = o;
+          } else {
+            for (int e = 0; e < 4 && n + e < p.n_store; ++e) orow[n + e] = (half_t)v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WN, int WM, int TN, int TM>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(const GemmArgs p) {
   constexpr int NT = WN * WM * 64;
   constexpr int BN = WN * TN * 32;
@@ -192,80 +271,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns pixel m = tile_m + r and, per register quad q, channels n..n+3 ---------------
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = m0 + (wm * TM + j) * 32 + r;
-    if (m >= p.M) continue;
-    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd : nullptr;
-    const half_t* rs = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
-    half_t* orow = p.out + (size_t)m * p.ldo;
-    if (p.act == MVOC_ACT_GEGLU) {
-      if constexpr (TN % 2 == 0) {
-#pragma unroll
-        for (int i = 0; i < TN; i += 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int nh = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;  // packed row of the value half
-            if (nh >= p.N) continue;
-            const int no = (n0 + (wn * TN + i) * 32) / 2 + 8 * q + 4 * h;
-            half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-            if (p.bias) {
-              bh = *reinterpret_cast<const half4_t*>(p.bias + nh);
-              bg = *reinterpret_cast<const half4_t*>(p.bias + nh + 32);
-            }
-            half4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float hv = r16(acc[i][j][q * 4 + e] + (float)bh[e]);
-              const float gv = r16(acc[i + 1][j][q * 4 + e] + (float)bg[e]);
-              float v = r16(hv * r16(gelu_erf_f(gv)));
-              if (rs) v = r16(v + (float)rs[no + e]);
-              o[e] = (half_t)v;
-            }
-            *reinterpret_cast<half4_t*>(orow + no) = o;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
-          if (n >= p.n_store) continue;
-          half4_t b4 = {0, 0, 0, 0};
-          if (p.bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
-          if (ra) {
-            const half4_t t4 = *reinterpret_cast<const half4_t*>(ra + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
-          }
-          if (p.act == MVOC_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
-          } else if (p.act == MVOC_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(gelu_erf_f(v[e]));
-          }
-          if (rs) {
-            const half4_t r4 = *reinterpret_cast<const half4_t*>(rs + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)r4[e]);
-          }
-          if (n + 4 <= p.n_store) {
-            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<half4_t*>(orow + n) = o;
-          } else {
-            for (int e = 0; e < 4 && n + e < p.n_store; ++e) orow[n + e] = (half_t)v[e];
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
 }
 
 template <int WN, int WM, int TN, int TM>
@@ -281,6 +287,171 @@ int launch(const GemmArgs& a0, hipStream_t s) {
   }
   hipLaunchKernelGGL((gemm_kernel<WN, WM, TN, TM>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
   return mvoc_check_launch("gemm_kernel");
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (global_load_lds_dwordx4): no staging registers, no ds_write pass; the loads of K-tile
+// t+1 are in flight while tile t is multiplied.  K step BKK (64): one barrier per 64-deep step.
+// An LDS-DMA wave-instruction writes 64 x 16 B CONTIGUOUSLY (wave-uniform base + lane*16), so rows cannot be
+// padded; bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and again on
+// the fragment read: 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7)  (BKK = 64: 128-byte rows;
+// ds_read_b128 slot = 8*(r&1) + position -> 16 distinct slots over any 16 rows with distinct r mod 16).
+// Zero padding of the conv / temporal gathers and M/N tails: the lane's source is a 16-byte zero constant.
+// ------------------------------------------------------------------------------------------------------------
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
+  constexpr int BKK = 64;
+  constexpr int NCH = BKK / 8;           // 16-byte chunks per row
+  constexpr int NW = WN * WM;            // waves
+  constexpr int BN = WN * TN * 32;
+  constexpr int BM = WM * TM * 32;
+  constexpr int IW = BN * NCH / 64;      // wave-instructions per K step for the weight tile
+  constexpr int IA = BM * NCH / 64;
+  static_assert(IW % NW == 0 && IA % NW == 0, "every wave issues the same number of LDS-DMA instructions");
+  constexpr int PW = IW / NW;
+  constexpr int PA = IA / NW;
+  constexpr int ROW = BKK * 2;           // bytes
+  constexpr int STAGE = (BN + BM) * ROW;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / WM, wm = wave % WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (int)(logical % (unsigned)p.n_tiles) * BN;
+  const int m0 = (int)(logical / (unsigned)p.n_tiles) * BM;
+  const half_t* zsrc = reinterpret_cast<const half_t*>(&g_zero16);
+
+  // lane -> (row within the 8-row group of an instruction, position); source chunk = pos ^ swizzle(row)
+  const int lrow = lane >> 3, pos = lane & 7;
+  // ---- weight side: instruction j = wave + i*NW covers rows j*8 .. j*8+7 -------------------------------
+  const half_t* wsrc[PW];
+  bool wok[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int row = (wave + i * NW) * 8 + lrow;
+    const int c = pos ^ ((row >> 1) & 7);
+    wok[i] = n0 + row < p.N;
+    wsrc[i] = p.w + (size_t)(wok[i] ? n0 + row : 0) * p.K + c * 8;
+  }
+  // ---- activation side (cin and c1 are multiples of 64: a K step never straddles a tap or a source) ----
+  int rm[PA], ry0[PA], rx0[PA], rimg[PA], cch[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave + i * NW) * 8 + lrow;
+    const int m = m0 + row;
+    rm[i] = m < p.M ? m : -1;
+    ry0[i] = rx0[i] = rimg[i] = 0;
+    const int mm = m < p.M ? m : 0;
+    if (p.a_mode == MVOC_A_CONV3X3) {
+      const int hwout = p.hout * p.wout;
+      const int img = mm / hwout;
+      const int rem = mm - img * hwout;
+      const int oy = rem / p.wout;
+      rimg[i] = img;
+      ry0[i] = oy * p.stride - 1;
+      rx0[i] = (rem - oy * p.wout) * p.stride - 1;
+    } else if (p.a_mode == MVOC_A_TEMPORAL3) {
+      rimg[i] = (mm / p.hw) % p.frames;
+    }
+    cch[i] = (pos ^ ((row >> 1) & 7)) * 8;
+  }
+  int tap = 0, ch0 = 0;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
+
+  auto issue = [&](int buf, int k0) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const half_t* src = wok[i] ? wsrc[i] + k0 : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+    // uniform part of the gather
+    const bool second = ch0 >= p.c1;
+    const half_t* sbase = second ? p.a2 : p.a;
+    const int ld = second ? p.lda2 : p.lda;
+    const int cbase = second ? ch0 - p.c1 : ch0;
+    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      bool ok = rm[i] >= 0;
+      long srow = rm[i] >= 0 ? rm[i] : 0;
+      if (p.a_mode == MVOC_A_TEMPORAL3) {
+        const int f2 = rimg[i] + tap - 1;
+        ok = ok && f2 >= 0 && f2 < p.frames;
+        srow += (long)(tap - 1) * p.hw;
+      } else if (p.a_mode == MVOC_A_CONV3X3) {
+        int iy = ry0[i] + ky, ix = rx0[i] + kx;
+        ok = ok && iy >= 0 && ix >= 0 && iy < p.hup && ix < p.wup;
+        if (p.upsample) {
+          iy = min((int)floorf(iy * p.ups_sh), p.hsrc - 1);
+          ix = min((int)floorf(ix * p.ups_sw), p.wsrc - 1);
+        }
+        srow = ((long)rimg[i] * p.hsrc + iy) * p.wsrc + ix;
+      }
+      const half_t* src = ok ? sbase + srow * ld + cbase + cch[i] : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + BN * ROW + (wave + i * NW) * 1024),
+                                       16, 0, 0);
+    }
+    ch0 += BKK;
+    if (ch0 >= p.cin) { ch0 = 0; ++tap; }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / BKK;
+  const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();  // tile kt has landed (the barrier's fence drains this wave's LDS-DMA), buffer cur^1 is free
+    if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BKK);
+    const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
+    const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = ((2 * s + h) ^ swz) * 16;
+      half8_t wf[TN], af[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
+}
+
+template <int WN, int WM, int TN, int TM>
+int launch_glds(const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+  a.n_tiles = (a.N + BN - 1) / BN;
+  a.m_tiles = (a.M + BM - 1) / BM;
+  const long nblk = (long)a.n_tiles * a.m_tiles;
+  if (nblk <= 0 || nblk > 0x7fffffffL) {
+    mvoc_set_error("gemm: grid of %ld blocks", nblk);
+    return -2;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
+  return mvoc_check_launch("gemm_glds_kernel");
 }
 
 }  // namespace
@@ -328,7 +499,16 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)d->m * (double)d->n * (double)d->k;
   MvocProfScope prof(MVOC_FAM_GEMM, s, flops);
+  const bool glds_ok = d->k % 64 == 0 && d->cin % 64 == 0 && d->c1 % 64 == 0 &&
+                       (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin);
   int tile = d->tile;
+  if (tile == 0 && glds_ok) {
+    if (d->act == MVOC_ACT_GEGLU) tile = 11;
+    else if (d->m <= 2048) tile = 13;
+    else if (d->n % 160 == 0) tile = 12;
+    else if (d->n % 128 == 0) tile = 11;
+    else tile = 13;
+  }
   if (tile == 0) {
     if (d->act == MVOC_ACT_GEGLU) tile = 1;
     else if (d->n % 160 == 0 && d->m >= 2048) tile = 2;
@@ -344,6 +524,16 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       if (d->act == MVOC_ACT_GEGLU) return launch<1, 4, 2, 1>(a, s);
       return launch<2, 2, 1, 2>(a, s);        // 64 x 128
     case 4: return launch<1, 4, 2, 1>(a, s);  // 64 x 128, waves along m
+    // direct-to-LDS variants (K step 64)
+    case 11:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 2, 2, 2>(a, s);  // 128 x 128
+    case 12:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 12 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 4, 5, 1>(a, s);  // 160 x 128
+    case 13:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<1, 4, 2, 1>(a, s);  // 64 x 128
     default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
   }
 }

@@ -35,13 +35,13 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
     maps (asymmetric data) are checked bit for bit"""
     g = torch.Generator().manual_seed(tile * 1000 + m)
-    n, k = 320, 96
+    n, k = 320, (192 if tile > 10 else 96)
     x = torch.randint(-3, 4, (m, k), generator=g).float()
     w = torch.randint(-3, 4, (n, k), generator=g).float()
     b = torch.randint(-8, 9, (n,), generator=g).float()
@@ -102,8 +102,11 @@ def _from_rows(r, n, h, w):
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2)
 
 
+@pytest.mark.parametrize("tile", [0, 11, 13])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 8, 8, 1), (32, 96, 7, 9, 1), (64, 128, 9, 6, 2), (8, 64, 8, 8, 1)])
-def test_conv3x3(ops, cin, cout, h, w, stride):
+def test_conv3x3(ops, cin, cout, h, w, stride, tile):
+    if tile and cin % 64:
+        pytest.skip("direct-to-LDS tiles need cin % 64 == 0")
     from mvoc_amd.unet import pack_conv3x3
     g = torch.Generator().manual_seed(cin + cout + h)
     n = 5
@@ -111,9 +114,25 @@ def test_conv3x3(ops, cin, cout, h, w, stride):
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half()
     b = torch.randn(cout, generator=g).half()
     ref = F.conv2d(x.float(), wt.float(), b.float(), stride=stride, padding=1)
-    out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, stride=stride, n_store=cout)
+    out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, stride=stride, n_store=cout,
+                              tile=tile)
     assert (ho, wo) == tuple(ref.shape[2:])
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("tile", [0, 11, 13])
+def test_conv3x3_concat_glds(ops, tile):
+    """two-source gather (decoder skip concat) with both channel counts multiples of 64"""
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(15)
+    n, c1, c2, cout, h, w = 4, 128, 64, 64, 7, 6
+    x1, x2 = torch.randn(n, c1, h, w, generator=g).half(), torch.randn(n, c2, h, w, generator=g).half()
+    wt = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / 40).half()
+    b = torch.randn(cout, generator=g).half()
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), wt.float(), b.float(), padding=1)
+    out, _, _ = ops.conv3x3(dev(_nhwc(x1)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, x2=dev(_nhwc(x2)), n_store=cout,
+                            tile=tile)
+    assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
 
 
 def test_conv3x3_concat_temb_resid(ops):
@@ -132,8 +151,9 @@ def test_conv3x3_concat_temb_resid(ops):
     assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("tile", [0, 13])
 @pytest.mark.parametrize("size", [None, (11, 7)])
-def test_conv3x3_upsample(ops, size):
+def test_conv3x3_upsample(ops, size, tile):
     from mvoc_amd.unet import pack_conv3x3
     g = torch.Generator().manual_seed(12)
     n, c, h, w = 3, 64, 6, 4
@@ -143,13 +163,14 @@ def test_conv3x3_upsample(ops, size):
     up = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if size is None else F.interpolate(x.float(), size=size, mode="nearest")
     ref = F.conv2d(up, wt.float(), b.float(), padding=1)
     out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w,
-                              upsample_to=size or (2 * h, 2 * w), n_store=c)
+                              upsample_to=size or (2 * h, 2 * w), n_store=c, tile=tile)
     assert (ho, wo) == tuple(ref.shape[2:])
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("tile", [0, 11, 13])
 @pytest.mark.parametrize("frames", [1, 3, 16])
-def test_tconv3(ops, frames):
+def test_tconv3(ops, frames, tile):
     from mvoc_amd.unet import pack_tconv
     g = torch.Generator().manual_seed(13 + frames)
     nb, c, hw = 2, 64, 12
@@ -158,7 +179,7 @@ def test_tconv3(ops, frames):
     b = torch.randn(c, generator=g).half()
     ref = F.conv3d(x.float(), wt.float(), b.float(), padding=(1, 0, 0)) + x.float()
     rows = x[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c)
-    out = ops.tconv3(dev(rows), pack_tconv(dev(wt)), dev(b), nvid=nb, frames=frames, hw=hw, resid=dev(rows))
+    out = ops.tconv3(dev(rows), pack_tconv(dev(wt)), dev(b), nvid=nb, frames=frames, hw=hw, resid=dev(rows), tile=tile)
     got = out.reshape(nb, frames, hw, c).permute(0, 3, 1, 2)[..., None]
     assert rel_l2(got, ref) < 1.5e-3
 
