@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Stage 1 of MVOC on MI355X: DDIM inversion of every active entry of a group config.  Same CLI, config keys,
+output files (``{output_dir}/ddim_latents_{t}.pt``) and call sequence as the reference's ``i2vgen-xl/inverse.py``.
+
+    PYTHONPATH=.. python inverse.py --template_config configs/group_inversion/template.yaml \
+                                    --configs_json configs/group_inversion/group_config.json [--synthetic] [--shard i/n]
+
+Entries are independent (reference loop ``inverse.py:136``); ``--shard i/n`` (or RANK/WORLD_SIZE from torchrun)
+gives every n-th active entry to this process, one process per GPU, no collectives.
+"""
+import argparse
+import json
+import logging
+import os
+from pathlib import Path
+
+import torch
+from PIL import Image
+
+from common import PRETRAINED_MODEL_PATH
+from mvoc_amd.config import OmegaConf
+from mvoc_amd.launch import my_entries, pick_device
+from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+from pipelines.pipeline_i2vgen_xl import I2VGenXLPipeline
+from utils import export_to_gif, load_ddim_latents_at_t, load_video_frames, seed_everything
+
+logger = logging.getLogger(__name__)
+
+
+def ddim_inversion(config, first_frame, frame_list, pipe, inverse_scheduler, g):
+    pipe.scheduler = inverse_scheduler
+    video_latents_at_0 = pipe.encode_vae_video(frame_list, device=pipe._execution_device, height=config.image_size[1],
+                                               width=config.image_size[0])
+    ddim_latents = pipe.invert(prompt=config.prompt, image=first_frame, height=config.image_size[1], width=config.image_size[0],
+                               num_frames=config.n_frames, num_inference_steps=config.n_steps, guidance_scale=config.cfg,
+                               negative_prompt=config.negative_prompt, target_fps=config.target_fps, latents=video_latents_at_0,
+                               generator=g, return_dict=False, output_dir=config.output_dir)
+    return ddim_latents[0]
+
+
+def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe, ddim_scheduler, ddim_init_latents_t_idx, g, output_type="pil"):
+    pipe.scheduler = ddim_scheduler
+    return pipe(prompt=config.prompt, image=first_frame, height=config.image_size[1], width=config.image_size[0],
+                num_frames=config.n_frames, num_inference_steps=config.n_steps, guidance_scale=config.cfg,
+                negative_prompt=config.negative_prompt, target_fps=config.target_fps, latents=ddim_latents_at_T, generator=g,
+                return_dict=True, ddim_init_latents_t_idx=ddim_init_latents_t_idx, output_type=output_type,
+                decode_chunk_size=1).frames[0]
+
+
+def build_pipeline(device, synthetic):
+    if synthetic or not os.path.isdir(os.path.join(PRETRAINED_MODEL_PATH, "unet")):
+        if not synthetic:
+            logger.warning(f"{PRETRAINED_MODEL_PATH}/unet not found: using seeded synthetic UNet weights")
+        return I2VGenXLPipeline.synthetic(device=device)
+    return I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=torch.float16, variant="fp16", device=device)
+
+
+def main(template_config, configs_list, device, synthetic=False):
+    pipe = build_pipeline(device, synthetic)
+    g = torch.Generator().manual_seed(template_config.seed)
+    inverse_scheduler = DDIMInverseScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
+    ddim_scheduler = DDIMScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
+    for entry in configs_list:
+        if not entry["active"]:
+            logger.info(f"Skipping config_entry: {entry}")
+            continue
+        config = OmegaConf.merge(template_config, OmegaConf.create(entry))
+        config.video_path = os.path.join(config.video_dir, config.video_name + ".mp4")
+        config.video_frames_path = os.path.join(config.video_dir, config.video_name)
+        logger.info(f"config: {OmegaConf.to_yaml(config)}")
+        _, frame_list = load_video_frames(config.video_frames_path, config.n_frames, config.image_size)
+        first_frame = frame_list[0]
+        if config.inverse_config.inverse_static_video:
+            frame_list = [frame_list[0]] * config.n_frames
+        if config.inverse_config.null_image_inversion:
+            first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
+        if os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False):
+            logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
+        else:
+            ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g)
+        recon = config.recon_config
+        if recon.enable_recon:
+            ddim_scheduler.set_timesteps(recon.n_steps)
+            t0 = ddim_scheduler.timesteps[recon.ddim_init_latents_t_idx]
+            lat = load_ddim_latents_at_t(int(t0), ddim_latents_path=recon.ddim_latents_path)
+            try:
+                video = ddim_sampling(recon, first_frame, lat, pipe, ddim_scheduler, recon.ddim_init_latents_t_idx, g)
+                os.makedirs(config.output_dir, exist_ok=True)
+                export_to_gif(video, os.path.join(config.output_dir, "ddim_reconstruction.gif"))
+            except NotImplementedError as e:  # no VAE decoder on this path: keep the reconstructed latents instead
+                logger.warning(f"reconstruction decoded to latents only ({e})")
+                video = ddim_sampling(recon, first_frame, lat, pipe, ddim_scheduler, recon.ddim_init_latents_t_idx, g, "latent")
+                os.makedirs(config.output_dir, exist_ok=True)
+                torch.save(video.cpu(), os.path.join(config.output_dir, "ddim_reconstruction_latents.pt"))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--template_config", type=str, default="configs/group_inversion/template.yaml")
+    ap.add_argument("--configs_json", type=str, default="configs/group_inversion/group_config.json")
+    ap.add_argument("--synthetic", action="store_true", help="seeded synthetic UNet weights + conditioning (no checkpoint)")
+    ap.add_argument("--shard", type=str, default=None, help="i/n: process entry k when k %% n == i")
+    args = ap.parse_args()
+    template_config = OmegaConf.load(args.template_config)
+    logging.basicConfig(level=logging.DEBUG if template_config.debug else logging.INFO,
+                        format="%(asctime)s - %(levelname)s - [%(funcName)s] - %(message)s")
+    assert Path(args.configs_json).exists()
+    with open(args.configs_json) as f:
+        configs_list = json.load(f)
+    device = pick_device(template_config.device, args.shard)
+    torch.set_grad_enabled(False)
+    seed_everything(template_config.seed)
+    main(template_config, my_entries(configs_list, args.shard), device, args.synthetic)

@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             for (int e = 0; e < 4; ++e) {
               const float hv = r16(acc[i][j][q * 4 + e] + (float)bh[e]);
               const float gv = r16(acc[i + 1][j][q * 4 + e] + (float)bg[e]);
-              float v = r16(hv * r16(gelu_erf_f(gv)));
+              float v = r16(hv * r16(gelu_fast_f(gv)));
               if (rs) v = r16(v + (float)rs[no + e]);
               o[e] = (half_t)v;
             }
@@ -110,7 +110,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
           } else if (p.act == MVOC_ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(gelu_erf_f(v[e]));
+            for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
           }
           if (rs) {
             const half4_t r4 = *reinterpret_cast<const half4_t*>(rs + n);

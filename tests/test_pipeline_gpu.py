@@ -1,0 +1,233 @@
+"""GPU: the three denoising loops (mvoc_amd.pipeline) against the oracle's loop restatement on a toy UNet, the
+graph-captured iteration against the eager one, and the drop-in drivers (i2vgen-xl/inverse.py, composite.py) end to end
+on a tiny synthetic group config.
+
+Tolerances (fp16 HIP vs fp32 CPU UNet inside an fp16 loop): latents after n<=5 DDIM steps max-abs <= 3e-2 (the
+per-step UNet tolerance of test_unet_gpu.py accumulated; values are O(1))."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pair():
+    from oracle import unet_ref as U
+    from mvoc_amd.unet import I2VGenXLUNet
+    o = U.I2VGenXLUNet(U.UNetConfig.small4())
+    U.init_weights_(o, seed=9)
+    for p in o.parameters():
+        p.copy_(p.half().float())
+    eng = I2VGenXLUNet(o.config.to_dict()).load_state_dict(o.state_dict())
+    return o, eng
+
+
+def _cond(g, b, f, h, w, cd=64):
+    return dict(pe=torch.randn(1, 7, cd, generator=g).half(), ne=torch.randn(1, 7, cd, generator=g).half(),
+                ie=torch.randn(1, 1, cd, generator=g).half(), il=torch.randn(1, 4, f, h, w, generator=g).half())
+
+
+@pytest.mark.parametrize("cfg", [1.0, 7.5])
+@pytest.mark.parametrize("graphs", [False, True])
+def test_invert_and_sample_vs_oracle(cfg, graphs, tmp_path):
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    o, eng = _pair()
+    g = torch.Generator().manual_seed(3)
+    f, h, w = 3, 8, 8
+    c = _cond(g, 1, f, h, w)
+    x0 = torch.randn(1, 4, f, h, w, generator=g).half()
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=graphs)
+    out_dir = str(tmp_path / "lat")
+    inv = pipe.invert(height=h * 8, width=w * 8, num_frames=f, num_inference_steps=5, guidance_scale=cfg, target_fps=8,
+                      latents=x0.cuda(), prompt_embeds=c["pe"].cuda(), negative_prompt_embeds=c["ne"].cuda(),
+                      image_embeddings=c["ie"].cuda(), image_latents=c["il"].cuda(), return_dict=False, output_dir=out_dir)
+    assert inv.shape == (1, 5, 4, f, h, w)
+
+    def unet_fn(inp, t):
+        b = inp.shape[0]
+        pe = torch.cat([c["ne"], c["pe"]]) if b == 2 else c["pe"]
+        ie = torch.cat([torch.zeros_like(c["ie"]), c["ie"]]) if b == 2 else c["ie"]
+        il = torch.cat([c["il"]] * b)
+        return o(inp.float(), int(t), torch.tensor([8] * b), il.float(), ie.float(), pe.float())[0].half()
+
+    saved, ref_seq = loops_ref.invert_loop(unet_fn, sched_ref.DDIMInverseSchedulerRef(), x0, 5, cfg)
+    assert (inv.cpu().float() - ref_seq.float()).abs().max() < 3e-2
+    # files: one per inverse timestep, holding the latent AT that noise level, fp16 [1,4,F,h,w]
+    ts = sorted(saved)
+    assert ts == [1, 201, 401, 601, 801]
+    for i, t in enumerate(ts):
+        lat = torch.load(os.path.join(out_dir, f"ddim_latents_{t}.pt"))
+        assert lat.dtype == torch.float16 and tuple(lat.shape) == (1, 4, f, h, w)
+        assert torch.equal(lat, inv[0, len(ts) - 1 - i][None].cpu())
+    # reconstruction sampling from the noisiest latent with the forward scheduler
+    pipe.scheduler = DDIMScheduler()
+    rec = pipe(height=h * 8, width=w * 8, num_frames=f, num_inference_steps=5, guidance_scale=cfg, target_fps=8,
+               latents=inv[:, 0], prompt_embeds=c["pe"].cuda(), negative_prompt_embeds=c["ne"].cuda(),
+               image_embeddings=c["ie"].cuda(), image_latents=c["il"].cuda(), output_type="latent", ddim_init_latents_t_idx=1).frames
+    ref = loops_ref.sample_loop(unet_fn, sched_ref.DDIMSchedulerRef(), inv[:, 0].cpu(), 5, cfg, ddim_init_latents_t_idx=1)
+    assert (rec.cpu().float() - ref.float()).abs().max() < 3e-2
+
+
+def test_graph_replay_equals_eager():
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    _, eng = _pair()
+    g = torch.Generator().manual_seed(4)
+    f, h, w = 2, 8, 8
+    c = _cond(g, 1, f, h, w)
+    x0 = torch.randn(1, 4, f, h, w, generator=g).half().cuda()
+    outs = []
+    for graphs in (False, True):
+        pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=graphs)
+        outs.append(pipe.invert(height=64, width=64, num_frames=f, num_inference_steps=4, guidance_scale=1.0, latents=x0,
+                                prompt_embeds=c["pe"].cuda(), negative_prompt_embeds=c["ne"].cuda(), image_embeddings=c["ie"].cuda(),
+                                image_latents=c["il"].cuda(), return_dict=False, output_dir=None))
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_composition_vs_oracle(graphs):
+    from oracle import loops_ref, sched_ref
+    from oracle.pnp_model_ref import PnPState, install_pnp
+    from mvoc_amd import pnp_utils
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMScheduler
+    o, eng = _pair()
+    g = torch.Generator().manual_seed(5)
+    f, h, w, cd, n = 3, 8, 8, 64, 5
+    cond = dict(encoder_hidden_states=torch.randn(5, 7, cd, generator=g).half(), image_embeddings=torch.randn(5, f, cd, generator=g).half(),
+                image_latents_first=torch.randn(5, 4, f, h, w, generator=g).half(), image_latents=torch.randn(5, 4, f, h, w, generator=g).half())
+    u8 = torch.randint(0, 256, (2, f, h, w), generator=g)
+    masks = [((u8[j].float() / 255).half()[None, None].repeat(1, 4, 1, 1, 1), (u8[j] > 10)[None, None].repeat(1, 4, 1, 1, 1)) for j in range(2)]
+    s = DDIMScheduler()
+    s.set_timesteps(n)
+    src = {(k, int(t)): torch.randn(1, 4, f, h, w, generator=g).half() for k in range(3) for t in s.timesteps}
+    x0 = torch.randn(1, 4, f, h, w, generator=g).half()
+    # ---- oracle: schedules as composite.init_pnp builds them (prefixes of the full timestep list)
+    rs = sched_ref.DDIMSchedulerRef()
+    rs.set_timesteps(n)
+    st = PnPState(conv_schedule=rs.timesteps[:1], spatial_schedule=rs.timesteps[:3], temporal_schedule=rs.timesteps[:4])
+    install_pnp(o, st)
+    st.masks = masks
+
+    def unet_fn(inp, t):
+        st.t = int(t)
+        return o.forward_ext(inp.float(), int(t), torch.tensor([8] * 5), cond["image_latents_first"].float(), cond["image_latents"].float(),
+                             cond["image_embeddings"].float(), cond["encoder_hidden_states"].float())[0].half()
+
+    ref = loops_ref.composition_loop(unet_fn, sched_ref.DDIMSchedulerRef(), x0, lambda t: src[(0, t)], lambda j, t: src[(1 + j, t)],
+                                     [m[0] for m in masks], n, guidance_scale=9.0, ddim_init_latents_t_idx=1, fusion_steps=(0, 2),
+                                     random_noise_ratio=0.3, obj_random_noise_fusion=True)
+    # ---- HIP pipeline
+    pipe = I2VGenXLPipeline(eng, DDIMScheduler(), use_graphs=graphs)
+    pnp_utils.register_temp_attention_pnp(pipe, s.timesteps[:4], False)
+    pnp_utils.register_spatial_attention_pnp(pipe, s.timesteps[:3], False)
+    pnp_utils.register_temp_conv_injection(pipe, s.timesteps[:1])
+    pnp_utils.register_out_conv_injection(pipe, s.timesteps[:1])
+    pnp_utils.register_resnet_injection(pipe, s.timesteps[:1])
+    for (k, t), v in src.items():
+        pipe.latent_cache.put(f"/virtual/src{k}", t, v.cuda())
+    pipe.latent_cache.write_files = False
+
+    class Cond:  # conditioner returning the prepared tensors in the reference's assembly order
+        def __init__(self):
+            self.k = {"p": 0}
+
+        def encode_prompt(self, prompt, negative_prompt=None):
+            if prompt == "edit":
+                return cond["encoder_hidden_states"][4:5].cuda(), cond["encoder_hidden_states"][3:4].cuda()
+            return cond["encoder_hidden_states"][0:1].cuda(), None
+
+        def image_latents(self, image, num_frames, height, width):
+            idx, fr, first = image
+            return cond["image_latents_first" if first else "image_latents"][idx:idx + 1].cuda()
+
+        def encode_image(self, image):
+            idx, fr, first = image
+            return cond["image_embeddings"][idx:idx + 1, fr:fr + 1].cuda()
+
+    pipe.conditioner = Cond()
+    pipe.latent_cache.write_files = False
+    # the reference assembles [bg, obj1, obj2, uncond(neg), cond]; inv prompts are identical for bg/objects
+    cond["encoder_hidden_states"][1] = cond["encoder_hidden_states"][0]
+    cond["encoder_hidden_states"][2] = cond["encoder_hidden_states"][0]
+    cond["image_embeddings"][3] = 0
+    cond["image_latents_first"][3] = cond["image_latents_first"][4]
+    cond["image_latents"][4] = cond["image_latents_first"][4]  # main branch: both built from the edited first frame (:1392-1410)
+    cond["image_latents"][3] = cond["image_latents"][4]
+    ref = loops_ref.composition_loop(unet_fn, sched_ref.DDIMSchedulerRef(), x0, lambda t: src[(0, t)], lambda j, t: src[(1 + j, t)],
+                                     [m[0] for m in masks], n, guidance_scale=9.0, ddim_init_latents_t_idx=1, fusion_steps=(0, 2),
+                                     random_noise_ratio=0.3, obj_random_noise_fusion=True)
+    out = pipe.sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection(
+        prompt="edit", main_first_image=(4, 0, True), main_image_list=[(4, k, False) for k in range(f)],
+        background_first_image=(0, 0, True), background_image_list=[(0, k, False) for k in range(f)],
+        objs_first_image=[(1, 0, True), (2, 0, True)],
+        objs_image_list=[[(1, k, False) for k in range(f)], [(2, k, False) for k in range(f)]],
+        height=h * 8, width=w * 8, num_frames=f, num_inference_steps=n, guidance_scale=9.0, negative_prompt="neg", target_fps=8,
+        latents=x0.cuda(), output_type="latent", ddim_init_latents_t_idx=1, ddim_inv_prompt="", fusion_steps=(0, 2),
+        random_noise_ratio=0.3, obj_random_noise_fusion=True, bg_inv_latents_path="/virtual/src0",
+        obj_ddim_latents_path=["/virtual/src1", "/virtual/src2"], obj_ddim_latents_idx_offset=[0, 0], obj_masks_tensors=masks).frames
+    d = (out.cpu().float() - ref.float()).abs().max()
+    assert d < 5e-2, float(d)
+
+
+def test_dropin_drivers_end_to_end(tmp_path):
+    """inverse.py then composite.py of this repo on a tiny hand-made group (3 videos), synthetic weights/conditioning"""
+    from PIL import Image
+    sys.path[:0] = [os.path.join(REPO, "i2vgen-xl"), REPO]
+    for m in ("utils", "pnp_utils", "inverse", "composite", "pipelines", "pipelines.pipeline_i2vgen_xl"):
+        sys.modules.pop(m, None)
+    import composite
+    import inverse
+    from mvoc_amd.config import OmegaConf
+    data = tmp_path
+    rng = np.random.default_rng(0)
+    for name in ("clipA", "clipB"):
+        d = data / "demo" / name / name
+        d.mkdir(parents=True)
+        for i in range(4):
+            Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / f"{i:05d}.png")
+        (d / "edited_first_frame").mkdir()
+        Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / "edited_first_frame" / "00000.png")
+        for mname in ("m1", "m2"):
+            md = data / "demo" / name / mname
+            md.mkdir()
+            for i in range(4):
+                m = np.zeros((64, 64), np.uint8)
+                m[8 + 4 * i:40 + 4 * i, 16:48] = 255
+                Image.fromarray(m).save(md / f"{i:05d}.png")
+    tmpl = OmegaConf.load(os.path.join(REPO, "tests", "data", "inversion_template.yaml"))
+    tmpl.data_dir = str(data)
+    entries = [{"active": True, "force_recompute_latents": True, "video_name": n, "video_dir": str(data / "demo" / n), "image_size": [64, 64],
+                "n_frames": 4, "recon_config": {"enable_recon": n == "clipA", "ddim_init_latents_t_idx": 1}} for n in ("clipA", "clipB")]
+    entries.append({"active": False, "video_name": "skipped"})
+    inverse.main(tmpl, entries, torch.device("cuda:0"), synthetic=True)
+    for n in ("clipA", "clipB"):
+        files = sorted(os.listdir(data / "inversions" / "i2vgen-xl" / n / "ddim_latents"))
+        assert files == sorted(f"ddim_latents_{t}.pt" for t in (1, 201, 401, 601, 801))
+    assert (data / "inversions" / "i2vgen-xl" / "clipA" / "ddim_reconstruction_latents.pt").exists()
+    ct = OmegaConf.load(os.path.join(REPO, "tests", "data", "composite_template.yaml"))
+    ct.data_dir = str(data)
+    centry = {"active": True, "task_name": "T", "video_name": "clipA", "image_size": [64, 64],
+              "edited_first_frame_path": "demo/clipA/clipA/edited_first_frame/00000.png", "editing_prompt": "a b", "edited_video_name": "out",
+              "ddim_init_latents_t_idx": 0, "pnp_f_t": 0.2, "pnp_spatial_attn_t": 1.0, "pnp_temp_attn_t": 1.0, "random_noise_ratio": 0.0,
+              "obj_mask_path": ["demo/clipA/m1", "demo/clipA/m2"], "obj_width_height": [[64, 64], [64, 64]],
+              "obj_ddim_latents_path": ["inversions/i2vgen-xl/clipA/ddim_latents", "inversions/i2vgen-xl/clipB/ddim_latents"],
+              "bg_ddim_latents_path": "inversions/i2vgen-xl/clipB/ddim_latents", "edited_contorl_frame_path_main": "demo/clipA/clipA",
+              "edited_contorl_frame_path_background": "demo/clipB/clipB", "edited_contorl_frame_path": ["demo/clipA/clipA", "demo/clipB/clipB"],
+              "fusion_step": [0, 1]}
+    composite.main(ct, [centry], torch.device("cuda:0"), synthetic=True)
+    out_root = data / "Results" / "T" / "i2vgen-xl" / "clipA" / "out"
+    sub = os.listdir(out_root)
+    assert sub == ["ddim_init_latents_t_idx_0_nsteps_5_cfg_9.0_pnpf0.2_pnps1.0_pnpt1.0_ratio0.0noise_fusion_step0-1"]
+    lat = torch.load(out_root / sub[0] / "video_latents.pt")
+    assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()

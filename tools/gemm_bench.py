@@ -44,10 +44,14 @@ out = eng.forward_ext(x, t, fps, il, il, ie, eh)[0]
 torch.cuda.synchronize()
 ops._gemm = orig
 # the recorded descriptors point at freed activations: re-point them at big scratch buffers of the right size
-scratch = torch.randn(400_000_000, device="cuda").half()
-scratch2 = torch.randn(200_000_000, device="cuda").half()
-outbuf = torch.empty(900_000_000, dtype=torch.float16, device="cuda")
-res = torch.randn(450_000_000, device="cuda").half()
+def need(d):
+    rows_a = d.m if d.a_mode != 1 else d.nimg * d.hsrc * d.wsrc
+    return rows_a * max(d.lda, 1) + 64, rows_a * max(d.lda2, 1) + 64, d.m * d.ldo + 64, d.m * max(d.ldr, 1) + 64
+mx = [max(need(d)[i] for d, _ in rec.values()) for i in range(4)]
+scratch = torch.empty(mx[0], device="cuda", dtype=torch.float16).normal_()
+scratch2 = torch.empty(mx[1], device="cuda", dtype=torch.float16).normal_()
+outbuf = torch.empty(mx[2], dtype=torch.float16, device="cuda")
+res = torch.empty(mx[3], device="cuda", dtype=torch.float16).normal_()
 rows = []
 tot_fl = 0
 for key, (d, cnt) in rec.items():
