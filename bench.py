@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mix", default="job", choices=["job", "inv", "comp"],
+                    help="diagnostics: time only inversion (B=1) or only composition (B=5) steps; the metric is --mix job")
     return ap.parse_args()
 
 
@@ -111,6 +113,7 @@ class Job:
         self.src = {(s, int(t)): torch.randn(shape, generator=g).to(dev, torch.float16) for s in range(3) for t in ts}
         self.comp_i = 0
         self._hooks_live = False
+        self.mix = "job"
 
     def inversion_step(self):
         if self._hooks_live:  # the two stages share one engine here: clear the composition's hook state
@@ -134,8 +137,11 @@ class Job:
         self._hooks_live = True
         self.pipe.composition_step(self.comp_state, t, bg, [o1, o2], self.comp_table[self.comp_index[t]], fuse)
 
+    def is_comp(self, k):
+        return {"job": k % 4 == 3, "inv": False, "comp": True}[self.mix]
+
     def step(self, k):
-        if k % 4 == 3:
+        if self.is_comp(k):
             self.composition_step()
         else:
             self.inversion_step()
@@ -157,7 +163,7 @@ def roofline_leg(job, steps):
     ops.prof_reset()
     ops.prof_enable(True)
     for k in range(steps):
-        ops.delay_us(60000 if k % 4 != 3 else 20000)
+        ops.delay_us(20000 if job.is_comp(k) else 60000)
         job.step(k)
     torch.cuda.synchronize()
     ops.prof_enable(False)
@@ -166,7 +172,7 @@ def roofline_leg(job, steps):
     pipe.use_graphs = saved
     job.inv_state["run"] = inv_run
     cfg = pipe.unet.config
-    n_inv = sum(1 for k in range(steps) if k % 4 != 3)
+    n_inv = sum(1 for k in range(steps) if not job.is_comp(k))
     n_comp = steps - n_inv
     alg = n_inv * unet_flops(cfg, 1, job.F, job.h, job.h)["total"] + n_comp * unet_flops(cfg, 5, job.F, job.h, job.h)["total"]
     g = fam["gemm"]
@@ -245,6 +251,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max-reduce only
 
     job = Job(device, args.frames, args.latent, not args.no_graphs)
+    job.mix = args.mix
     # prime every graph variant the timed region will replay, then W untimed warm-up steps
     for k in range(4):
         job.step(k)

@@ -301,7 +301,7 @@ int launch(const GemmArgs& a0, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int WN, int WM, int TN, int TM>
+template <int WN, int WM, int TN, int TM, int NST>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
   constexpr int BKK = 64;
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
@@ -310,12 +310,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   constexpr int BM = WM * TM * 32;
   constexpr int IW = BN * NCH / 64;      // wave-instructions per K step for the weight tile
   constexpr int IA = BM * NCH / 64;
-  static_assert(IW % NW == 0 && IA % NW == 0, "every wave issues the same number of LDS-DMA instructions");
-  constexpr int PW = IW / NW;
+  static_assert(IA % NW == 0, "every wave issues the same number of activation LDS-DMA instructions");
+  static_assert(NST == 2 || IW % NW == 0, "the counted-vmcnt ring needs a uniform LDS-DMA count per wave");
+  constexpr int PW = (IW + NW - 1) / NW;
   constexpr int PA = IA / NW;
   constexpr int ROW = BKK * 2;           // bytes
   constexpr int STAGE = (BN + BM) * ROW;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   for (int i = 0; i < PW; ++i) {
     const int row = (wave + i * NW) * 8 + lrow;
     const int c = pos ^ ((row >> 1) & 7);
-    wok[i] = n0 + row < p.N;
+    wok[i] = row < BN && n0 + row < p.N;
     wsrc[i] = p.w + (size_t)(wok[i] ? n0 + row : 0) * p.K + c * 8;
   }
   // ---- activation side (cin and c1 are multiples of 64: a K step never straddles a tap or a source) ----
@@ -369,8 +370,9 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const half_t* src = wok[i] ? wsrc[i] + k0 : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+      if (IW % NW == 0 || wave + i * NW < IW)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
     }
     // uniform part of the gather
     const bool second = ch0 >= p.c1;
@@ -415,10 +417,24 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   const int nk = p.K / BKK;
   const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
   issue(0, 0);
+  if (NST == 3 && nk > 1) issue(1, BKK);
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();  // tile kt has landed (the barrier's fence drains this wave's LDS-DMA), buffer cur^1 is free
-    if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BKK);
+    if constexpr (NST == 2) {
+      __syncthreads();  // tile kt has landed (the barrier's fence drains this wave's LDS-DMA), buffer cur^1 is free
+      if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BKK);
+    } else {
+      // 3-stage ring, two K steps in flight: wait until only the NEWEST tile's PW+PA LDS-DMAs of this wave are
+      // outstanding (vmcnt counts in issue order), then a raw barrier (no fence => no vmcnt(0) drain): every wave's
+      // share of tile kt has landed and every wave is done reading the buffer tile kt+2 is about to overwrite.
+      if (kt + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + PA) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, (kt + 2) * BKK);
+    }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
 #pragma unroll
@@ -435,11 +451,12 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
 }
 
-template <int WN, int WM, int TN, int TM>
+template <int WN, int WM, int TN, int TM, int NST = 2>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -450,7 +467,7 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
   return mvoc_check_launch("gemm_glds_kernel");
 }
 
@@ -534,6 +551,22 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 13:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
       return launch_glds<1, 4, 2, 1>(a, s);  // 64 x 128
+    case 14:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 14 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 8, 5, 1>(a, s);  // 160 x 256, 8 waves
+    case 15:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 4, 2, 2>(a, s);  // 128 x 256, 8 waves
+    // 3-stage ring, counted vmcnt (two K steps in flight)
+    case 21:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 2, 2, 2, 3>(a, s);
+    case 22:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 22 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 4, 5, 1, 3>(a, s);
+    case 23:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<1, 4, 2, 1, 3>(a, s);
     default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
   }
 }

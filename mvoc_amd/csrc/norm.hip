@@ -78,39 +78,56 @@ __global__ __launch_bounds__(256) void gn_partial(const GnArgs p) {
   }
 }
 
-// Chan-combine the slab partials of one sample.  256 threads: lane = tid / G walks a strided subset of the slabs
-// for group g = tid % G (independent loads stay in flight), then lane 0 merges the per-lane results in fixed order.
-__global__ __launch_bounds__(256) void gn_final(const GnArgs p) {
-  __shared__ float ln[256], lmean[256], lm2[256];
+// Chan-combine the slab partials of one sample (deterministic: fixed slab->lane assignment, fixed merge tree).
+// 1024 threads: lane = tid / G walks slabs lane, lane+L, ...; the loads of 8 slabs are issued before any of them is
+// consumed (the merge arithmetic is a dependent chain, the loads are not), then the lanes merge pairwise in LDS.
+struct GnMoments { float n, mean, m2; };
+__device__ __forceinline__ void gn_merge(GnMoments& a, float nb, float mb, float m2b) {
+  if (nb <= 0.f) return;
+  const float nt = a.n + nb, delta = mb - a.mean;
+  a.mean += delta * (nb / nt);
+  a.m2 += m2b + delta * delta * (a.n * nb / nt);
+  a.n = nt;
+}
+
+__global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
+  __shared__ float ln[1024], lmean[1024], lm2[1024];
   const int tid = threadIdx.x, smp = blockIdx.x;
-  const int lanes = 256 / p.G;
+  int lanes = 1;
+  while (lanes * 2 * p.G <= 1024) lanes *= 2;  // power of two
   const int g = tid % p.G, lane = tid / p.G;
-  float n = 0.f, mean = 0.f, m2 = 0.f;
+  GnMoments acc = {0.f, 0.f, 0.f};
   if (lane < lanes) {
-    for (int c = lane; c < p.nchunk; c += lanes) {
-      const float* in = p.ws + (((long)smp * p.nchunk + c) * p.G + g) * 3;
-      const float nb = in[0], mb = in[1], m2b = in[2];
-      if (nb <= 0.f) continue;
-      const float nt = n + nb, delta = mb - mean;
-      mean += delta * (nb / nt);
-      m2 += m2b + delta * delta * (n * nb / nt);
-      n = nt;
+    const float* base = p.ws + ((long)smp * p.nchunk * p.G + g) * 3;
+    for (int c0 = lane; c0 < p.nchunk; c0 += lanes * 8) {
+      float nb[8], mb[8], qb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u * lanes;
+        nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
+        if (c < p.nchunk) {
+          const float* in = base + (long)c * p.G * 3;
+          nb[u] = in[0]; mb[u] = in[1]; qb[u] = in[2];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gn_merge(acc, nb[u], mb[u], qb[u]);
     }
   }
-  ln[tid] = n; lmean[tid] = mean; lm2[tid] = m2;
+  ln[tid] = acc.n; lmean[tid] = acc.mean; lm2[tid] = acc.m2;
   __syncthreads();
-  if (lane == 0) {
-    for (int l = 1; l < lanes; ++l) {
-      const float nb = ln[l * p.G + g], mb = lmean[l * p.G + g], m2b = lm2[l * p.G + g];
-      if (nb <= 0.f) continue;
-      const float nt = n + nb, delta = mb - mean;
-      mean += delta * (nb / nt);
-      m2 += m2b + delta * delta * (n * nb / nt);
-      n = nt;
+  for (int half = lanes / 2; half >= 1; half /= 2) {
+    if (lane < half) {
+      const int o = (lane + half) * p.G + g;
+      gn_merge(acc, ln[o], lmean[o], lm2[o]);
+      ln[tid] = acc.n; lmean[tid] = acc.mean; lm2[tid] = acc.m2;
     }
+    __syncthreads();
+  }
+  if (lane == 0) {
     float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + ((long)smp * p.G + g) * 2;
-    fin[0] = mean;
-    fin[1] = rsqrtf(m2 / n + p.eps);
+    fin[0] = acc.mean;
+    fin[1] = rsqrtf(acc.m2 / acc.n + p.eps);
   }
 }
 
@@ -250,7 +267,7 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
   MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
   dim3 grid(a.nchunk, a.nsample);
   hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");
 }
