@@ -62,6 +62,9 @@ typedef struct mvoc_gemm_desc {
   int32_t frames, hw;
   int32_t act;          /* MVOC_ACT_* */
   int32_t tile;         /* 0 = auto; otherwise force a tile config id (tuning) */
+  int32_t split_k;      /* 0 = auto, 1 = off, n = force n K-slices (needs workspace; direct-to-LDS tiles only) */
+  void* workspace;      /* optional fp32 scratch for split-K partial slabs: split_k * m * n * 4 bytes */
+  size_t workspace_bytes;
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);

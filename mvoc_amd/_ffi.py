@@ -26,7 +26,8 @@ class GemmDesc(C.Structure):
                 ("m", i64), ("n", i64), ("k", i64), ("n_store", i32), ("ldo", i32), ("ldr", i32), ("ld_rowadd", i32),
                 ("rowadd_div", i32), ("a_mode", i32), ("lda", i32), ("lda2", i32), ("c1", i32), ("cin", i32),
                 ("nimg", i32), ("hout", i32), ("wout", i32), ("hsrc", i32), ("wsrc", i32), ("stride", i32),
-                ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32)]
+                ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz)]
 
 
 class AttnDesc(C.Structure):

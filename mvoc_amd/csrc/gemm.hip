@@ -42,6 +42,8 @@ struct GemmArgs {
   int frames, hw;
   int act;
   int n_tiles, m_tiles;
+  int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
+  float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
 };
 
 struct RowInfo {   // per staged activation row (fixed for the whole K loop)
@@ -324,9 +326,12 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   const int wn = wave / WM, wm = wave % WM;
   const int r = lane & 31, h = lane >> 5;
 
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = (int)(logical0 % (unsigned)p.split_k);
+  const unsigned logical = logical0 / (unsigned)p.split_k;
   const int n0 = (int)(logical % (unsigned)p.n_tiles) * BN;
   const int m0 = (int)(logical / (unsigned)p.n_tiles) * BM;
+  const int kbeg = slice * p.k_per_split;
   const half_t* zsrc = reinterpret_cast<const half_t*>(&g_zero16);
 
   // lane -> (row within the 8-row group of an instruction, position); source chunk = pos ^ swizzle(row)
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     cch[i] = (pos ^ ((row >> 1) & 7)) * 8;
   }
-  int tap = 0, ch0 = 0;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
+  int tap = kbeg / p.cin, ch0 = kbeg - tap * p.cin;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
 
   auto issue = [&](int buf, int k0) {
     char* base = smem + buf * STAGE;
@@ -414,15 +419,15 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = p.K / BKK;
+  const int nk = p.k_per_split / BKK;
   const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
-  issue(0, 0);
-  if (NST == 3 && nk > 1) issue(1, BKK);
+  issue(0, kbeg);
+  if (NST == 3 && nk > 1) issue(1, kbeg + BKK);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (NST == 2) {
       __syncthreads();  // tile kt has landed (the barrier's fence drains this wave's LDS-DMA), buffer cur^1 is free
-      if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BKK);
+      if (kt + 1 < nk) issue(cur ^ 1, kbeg + (kt + 1) * BKK);
     } else {
       // 3-stage ring, two K steps in flight: wait until only the NEWEST tile's PW+PA LDS-DMAs of this wave are
       // outstanding (vmcnt counts in issue order), then a raw barrier (no fence => no vmcnt(0) drain): every wave's
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, (kt + 2) * BKK);
+      if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, kbeg + (kt + 2) * BKK);
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
@@ -453,7 +458,62 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
+  if (p.split_k > 1) {  // raw fp32 partials; bias / activation / residual happen in splitk_reduce_kernel
+    float* slab = p.ws + (size_t)slice * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + (wm * TM + j) * 32 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+          if (n >= p.N) continue;
+          f32x4 v = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = v;
+        }
+    }
+    return;
+  }
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
+}
+
+// sums the split-K slabs in slice order (deterministic) and applies the GEMM epilogue; thread = 4 consecutive n of a row
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N / 4;
+  if (idx >= (long)p.M * n4) return;
+  const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+  if (n >= p.n_store) return;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.split_k; ++s) a += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.N + n);
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = r16(a[e] + (p.bias ? (float)p.bias[n + e] : 0.f));
+  if (p.rowadd) {
+    const half_t* ra = p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)ra[n + e]);
+  }
+  if (p.act == MVOC_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+  } else if (p.act == MVOC_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
+  }
+  if (p.resid) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)p.resid[(size_t)m * p.ldr + n + e]);
+  }
+  half_t* o = p.out + (size_t)m * p.ldo + n;
+  if (n + 4 <= p.n_store) {
+    half4_t o4 = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4_t*>(o) = o4;
+  } else {
+    for (int e = 0; e < 4 && n + e < p.n_store; ++e) o[e] = (half_t)v[e];
+  }
 }
 
 template <int WN, int WM, int TN, int TM, int NST = 2>
@@ -467,7 +527,11 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
+  if (a.split_k > 1) {
+    const long nthr = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+  }
   return mvoc_check_launch("gemm_glds_kernel");
 }
 
@@ -499,6 +563,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   a.ups_sh = d->upsample ? (float)d->hsrc / (float)d->hup : 1.f;
   a.ups_sw = d->upsample ? (float)d->wsrc / (float)d->wup : 1.f;
   a.frames = d->frames; a.hw = d->hw; a.act = d->act;
+  a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
   if (d->a_mode == MVOC_A_CONV3X3) {
     MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
     MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");
@@ -521,7 +586,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   int tile = d->tile;
   if (tile == 0 && glds_ok) {
     if (d->act == MVOC_ACT_GEGLU) tile = 11;
-    else if (d->m <= 2048) tile = 13;
+    else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) tile = 13;  // few rows and no split-K: small tiles
     else if (d->n % 160 == 0) tile = 12;
     else if (d->n % 128 == 0) tile = 11;
     else tile = 13;
@@ -531,6 +596,21 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     else if (d->n % 160 == 0 && d->m >= 2048) tile = 2;
     else if (d->n % 128 == 0 && d->m >= 2048) tile = 1;
     else tile = 3;
+  }
+  if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1) {
+    // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
+    const int bm = tile == 14 || tile == 15 ? 256 : 128;
+    const int bn = (tile % 10 == 2 || tile == 14) ? 160 : (tile % 10 == 3 ? 64 : 128);
+    const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
+    int sk = d->split_k > 1 ? d->split_k : 1;
+    if (d->split_k == 0 && blocks < 384) {
+      while (sk < 8 && blocks * sk < 512 && d->k % (64 * sk * 2) == 0 && d->k / (sk * 2) >= 512) sk *= 2;
+    }
+    if (sk > 1 && d->k % (64 * sk) == 0 && (size_t)sk * d->m * d->n * 4 <= d->workspace_bytes) {
+      a.split_k = sk;
+      a.k_per_split = (int)(d->k / sk);
+      a.ws = (float*)d->workspace;
+    }
   }
   switch (tile) {
     case 1: return launch<2, 2, 2, 2>(a, s);  // 128 x 128

@@ -41,7 +41,11 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
-def _gemm(d: GemmDesc):
+def _gemm(d: GemmDesc, dev=None):
+    # problems with few output tiles and a deep K get a scratch for deterministic split-K (see gemm.hip)
+    if dev is not None and d.m <= 8192 and d.k >= 2048 and d.act != ACT_GEGLU and d.split_k != 1:
+        ws = torch.empty(8 * d.m * d.n, dtype=torch.float32, device=dev)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     check(lib.mvoc_gemm_f16(C.byref(d), _stream()), "gemm")
 
 
@@ -67,7 +71,8 @@ def _out_cols(w, n_store, act):
     return n_store if n_store else w.shape[0]
 
 
-def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0):
+def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0,
+           split_k=0):
     """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
     _rowmajor(x, "x")
@@ -85,12 +90,13 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
     d.a_mode = A_PLAIN
     d.c1 = k1
     d.cin = k1 + k2
-    _gemm(d)
+    d.split_k = split_k
+    _gemm(d, x.device)
     return out
 
 
 def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
-            n_store=0, out=None, tile=0):
+            n_store=0, out=None, tile=0, split_k=0):
     """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
     ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
@@ -112,11 +118,12 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
     d.nimg, d.hout, d.wout, d.hsrc, d.wsrc, d.stride = nimg, ho, wo, h, wd, stride
     d.upsample = 1 if upsample_to is not None else 0
     d.hup, d.wup = hup, wup
-    _gemm(d)
+    d.split_k = split_k
+    _gemm(d, x.device)
     return out, ho, wo
 
 
-def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0):
+def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_k=0):
     """Conv3d (3,1,1), pad (1,0,0), on x [nvid*frames*hw, C]; w [N, 3*C] tap-major."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(resid, "resid")
     _rowmajor(x, "x")
@@ -129,7 +136,8 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0):
     d.a_mode = A_TEMPORAL3
     d.c1 = d.cin = x.shape[1]
     d.frames, d.hw = frames, hw
-    _gemm(d)
+    d.split_k = split_k
+    _gemm(d, x.device)
     return out
 
 

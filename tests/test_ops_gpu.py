@@ -64,6 +64,38 @@ def test_linear_random(ops, n, k):
     assert (out.float().cpu() - ref).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("split_k", [2, 4, 0])
+def test_split_k(ops, split_k):
+    """deterministic split-K (fp32 slabs summed in slice order): conv with temb row-add + residual, temporal conv, linear"""
+    from mvoc_amd.unet import pack_conv3x3, pack_tconv
+    g = torch.Generator().manual_seed(50 + split_k)
+    n, c, cout, h, w, fr = 4, 256, 128, 8, 8, 2
+    x = torch.randn(n, c, h, w, generator=g).half()
+    wt = (torch.randn(cout, c, 3, 3, generator=g) / 48).half()
+    b = torch.randn(cout, generator=g).half()
+    temb = torch.randn(n // fr, cout, generator=g).half()
+    res = torch.randn(n, cout, h, w, generator=g).half()
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1) + temb.float().repeat_interleave(fr, 0)[:, :, None, None] + res.float()
+    out, _, _ = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, rowadd=dev(temb), rowadd_div=fr * h * w,
+                            resid=dev(_nhwc(res)), n_store=cout, split_k=split_k)
+    assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
+    out2, _, _ = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, rowadd=dev(temb), rowadd_div=fr * h * w,
+                             resid=dev(_nhwc(res)), n_store=cout, split_k=split_k)
+    assert torch.equal(out, out2)  # run-to-run reproducible
+    m, k, nn = 300, 2048, 192
+    a = torch.randn(m, k, generator=g).half()
+    wl = (torch.randn(nn, k, generator=g) / 45).half()
+    o = ops.linear(dev(a), dev(wl), None, split_k=split_k, act=ops.ACT_SILU)
+    assert rel_l2(o, F.silu((a.float() @ wl.float().t()).half().float())) < 2e-3
+    nb, cc, frames, hw = 1, 768, 4, 16
+    xt = torch.randn(nb, cc, frames, hw, 1, generator=g).half()
+    wt3 = (torch.randn(cc, cc, 3, 1, 1, generator=g) / 48).half()
+    rows = xt[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, cc)
+    reft = F.conv3d(xt.float(), wt3.float(), None, padding=(1, 0, 0))
+    ot = ops.tconv3(dev(rows), pack_tconv(dev(wt3)), None, nvid=nb, frames=frames, hw=hw, split_k=split_k)
+    assert rel_l2(ot.reshape(nb, frames, hw, cc).permute(0, 3, 1, 2)[..., None], reft) < 1.5e-3
+
+
 def test_linear_concat_and_acts(ops):
     g = torch.Generator().manual_seed(5)
     m, k1, k2, n = 300, 128, 64, 192
