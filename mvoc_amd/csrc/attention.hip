@@ -106,38 +106,41 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
-    const bool tail = (kt == ntiles - 1) && (p.tk & 63);
-    float mx = -INFINITY;
+    // online softmax on the raw scores; exp2(c*s - c*m) is one v_fma + one raw v_exp_f32 per element
+    if (__builtin_amdgcn_readfirstlane((kt == ntiles - 1) && (p.tk & 63))) {  // ragged last tile: mask keys >= tk
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3) >= p.tk) st[t][e] = -INFINITY;
+    }
+    float mx = st[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float sv = st[t][e] * p.scale_log2;
-        if (tail) {
-          const int key = kt * 64 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3);
-          if (key >= p.tk) sv = -INFINITY;
-        }
-        st[t][e] = sv;
-        mx = fmaxf(mx, sv);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(mrun, mx);
-    const float alpha = exp2f(mrun - mnew);
-    mrun = mnew;
+    if (__any(mx > mrun)) {  // wave-uniform: rescale the running state only when some query's maximum grew
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2);
+      mrun = mnew;
+      lrun *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
+    }
+    const float mc = mrun * p.scale_log2;
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = exp2f(st[t][e] - mnew);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][e], p.scale_log2, -mc));
         st[t][e] = pv;
         ps += pv;
       }
-    lrun = lrun * alpha + ps;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
+    lrun += ps;
 
     // O^T += V^T P^T : accumulator registers 8s..8s+7 of tile t are the column operand of k-step (t, s)
 #pragma unroll
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int key = 8 * (e >> 2) + 4 * h + (e & 3);
-    const float sv = key < F ? st[e] * p.scale_log2 : -INFINITY;
+    const float sv = key < F ? st[e] * p.scale_log2 : -INFINITY;  // F <= 32 keys: one tile, no running state
     st[e] = sv;
     mx = fmaxf(mx, sv);
   }
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
   float ps = 0.f;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const float pv = exp2f(st[e] - mx);
+    const float pv = __builtin_amdgcn_exp2f(st[e] - mx);
     st[e] = pv;
     ps += pv;
   }
