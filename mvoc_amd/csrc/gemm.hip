@@ -347,62 +347,80 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     wsrc[i] = p.w + (size_t)(wok[i] ? n0 + row : 0) * p.K + c * 8;
   }
   // ---- activation side (cin and c1 are multiples of 64: a K step never straddles a tap or a source) ----
-  int rm[PA], ry0[PA], rx0[PA], rimg[PA], cch[PA];
+  // Per staged row everything tap-independent is hoisted out of the K loop (the loop body was issue-bound on this
+  // address arithmetic: ~7 VALU + 6 SALU per MFMA before): a signed source-row offset of the row for tap (0,0) and a
+  // 9-bit mask of the taps that fall inside the image.  Per K step the wave-uniform tap adds a scalar row offset.
+  int rowoff[PA], cch[PA];
+  unsigned vmask[PA];
+  int ry0[PA], rx0[PA], rimg[PA];  // only the upsample path still needs coordinates
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int row = (wave + i * NW) * 8 + lrow;
     const int m = m0 + row;
-    rm[i] = m < p.M ? m : -1;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
     ry0[i] = rx0[i] = rimg[i] = 0;
-    const int mm = m < p.M ? m : 0;
+    rowoff[i] = mm;
+    vmask[i] = live ? 1u : 0u;
     if (p.a_mode == MVOC_A_CONV3X3) {
       const int hwout = p.hout * p.wout;
       const int img = mm / hwout;
       const int rem = mm - img * hwout;
       const int oy = rem / p.wout;
-      rimg[i] = img;
-      ry0[i] = oy * p.stride - 1;
-      rx0[i] = (rem - oy * p.wout) * p.stride - 1;
+      const int y0 = oy * p.stride - 1, x0 = (rem - oy * p.wout) * p.stride - 1;
+      rimg[i] = img; ry0[i] = y0; rx0[i] = x0;
+      rowoff[i] = (img * p.hsrc + y0) * p.wsrc + x0;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y0 + t / 3, ix = x0 + t % 3;
+        if (live && iy >= 0 && ix >= 0 && iy < p.hup && ix < p.wup) mk |= 1u << t;
+      }
+      vmask[i] = mk;
     } else if (p.a_mode == MVOC_A_TEMPORAL3) {
-      rimg[i] = (mm / p.hw) % p.frames;
+      const int f = (mm / p.hw) % p.frames;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (live && f + t - 1 >= 0 && f + t - 1 < p.frames) mk |= 1u << t;
+      vmask[i] = mk;
     }
     cch[i] = (pos ^ ((row >> 1) & 7)) * 8;
   }
   int tap = kbeg / p.cin, ch0 = kbeg - tap * p.cin;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
+  // weight pointers advance by one K step per issue; rows beyond N read the zero constant with stride 0
+  const half_t* wptr[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) wptr[i] = wok[i] ? wsrc[i] + kbeg : zsrc;
 
-  auto issue = [&](int buf, int k0) {
+  auto issue = [&](int buf) {
     char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-      const half_t* src = wok[i] ? wsrc[i] + k0 : zsrc;
       if (IW % NW == 0 || wave + i * NW < IW)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[i],
                                          (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+      wptr[i] += wok[i] ? BKK : 0;
     }
-    // uniform part of the gather
+    // wave-uniform part of the gather (scalar registers)
     const bool second = ch0 >= p.c1;
     const half_t* sbase = second ? p.a2 : p.a;
     const int ld = second ? p.lda2 : p.lda;
     const int cbase = second ? ch0 - p.c1 : ch0;
     const int ky = tap / 3, kx = tap - ky * 3;
+    int tap_rows = 0;
+    if (p.a_mode == MVOC_A_CONV3X3) tap_rows = ky * p.wsrc + kx;
+    else if (p.a_mode == MVOC_A_TEMPORAL3) tap_rows = (tap - 1) * p.hw;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      bool ok = rm[i] >= 0;
-      long srow = rm[i] >= 0 ? rm[i] : 0;
-      if (p.a_mode == MVOC_A_TEMPORAL3) {
-        const int f2 = rimg[i] + tap - 1;
-        ok = ok && f2 >= 0 && f2 < p.frames;
-        srow += (long)(tap - 1) * p.hw;
-      } else if (p.a_mode == MVOC_A_CONV3X3) {
-        int iy = ry0[i] + ky, ix = rx0[i] + kx;
-        ok = ok && iy >= 0 && ix >= 0 && iy < p.hup && ix < p.wup;
-        if (p.upsample) {
-          iy = min((int)floorf(iy * p.ups_sh), p.hsrc - 1);
-          ix = min((int)floorf(ix * p.ups_sw), p.wsrc - 1);
-        }
+      const bool ok = (vmask[i] >> tap) & 1u;
+      long srow = rowoff[i] + tap_rows;
+      if (p.upsample) {  // nearest-upsampled source: the row is not affine in the tap
+        const int iy = min((int)floorf((ry0[i] + ky) * p.ups_sh), p.hsrc - 1);
+        const int ix = min((int)floorf((rx0[i] + kx) * p.ups_sw), p.wsrc - 1);
         srow = ((long)rimg[i] * p.hsrc + iy) * p.wsrc + ix;
       }
-      const half_t* src = ok ? sbase + srow * ld + cbase + cch[i] : zsrc;
+      const half_t* src = ok ? sbase + srow * ld + (cbase + cch[i]) : zsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + BN * ROW + (wave + i * NW) * 1024),
                                        16, 0, 0);
@@ -421,13 +439,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
 
   const int nk = p.k_per_split / BKK;
   const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
-  issue(0, kbeg);
-  if (NST == 3 && nk > 1) issue(1, kbeg + BKK);
+  issue(0);
+  if (NST == 3 && nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (NST == 2) {
       __syncthreads();  // tile kt has landed (the barrier's fence drains this wave's LDS-DMA), buffer cur^1 is free
-      if (kt + 1 < nk) issue(cur ^ 1, kbeg + (kt + 1) * BKK);
+      if (kt + 1 < nk) issue(cur ^ 1);
     } else {
       // 3-stage ring, two K steps in flight: wait until only the NEWEST tile's PW+PA LDS-DMAs of this wave are
       // outstanding (vmcnt counts in issue order), then a raw barrier (no fence => no vmcnt(0) drain): every wave's
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1, kbeg + (kt + 2) * BKK);
+      if (kt + 2 < nk) issue(cur == 0 ? 2 : cur - 1);
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
