@@ -303,7 +303,7 @@ int launch(const GemmArgs& a0, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int WN, int WM, int TN, int TM, int NST>
+template <int WN, int WM, int TN, int TM, int NST, bool PF = false>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
   constexpr int BKK = 64;
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
@@ -460,19 +460,48 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
+    if constexpr (!PF) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int off = ((2 * s + h) ^ swz) * 16;
-      half8_t wf[TN], af[TM];
+      for (int s = 0; s < 4; ++s) {
+        const int off = ((2 * s + h) ^ swz) * 16;
+        half8_t wf[TN], af[TM];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
+        for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // software-pipelined fragments: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s
+      half8_t wf[2][TN], af[2][TM];
+      {
+        const int off = (h ^ swz) * 16;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[0][i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) af[0][j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+          const int off = ((2 * (s + 1) + h) ^ swz) * 16;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[(s + 1) & 1][i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) af[(s + 1) & 1][j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s & 1][i], af[s & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
@@ -534,7 +563,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <int WN, int WM, int TN, int TM, int NST = 2>
+template <int WN, int WM, int TN, int TM, int NST = 2, bool PF = false>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -545,7 +574,7 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
   if (a.split_k > 1) {
     const long nthr = (long)a.M * (a.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -602,9 +631,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   const bool glds_ok = d->k % 64 == 0 && d->cin % 64 == 0 && d->c1 % 64 == 0 &&
                        (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin);
   int tile = d->tile;
-  if (tile == 0 && glds_ok) {
-    if (d->act == MVOC_ACT_GEGLU) tile = 11;
+  if (tile == 0 && glds_ok) {  // measured per shape on MI355X (tools/gemm_bench.py)
+    if (d->act == MVOC_ACT_GEGLU) tile = d->m >= 8192 ? 15 : 11;
     else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) tile = 13;  // few rows and no split-K: small tiles
+    else if (d->m <= 8192 && d->n % 128 == 0) tile = 11;
     else if (d->n % 160 == 0) tile = 12;
     else if (d->n % 128 == 0) tile = 11;
     else tile = 13;
@@ -617,8 +647,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
-    const int bm = tile == 14 || tile == 15 ? 256 : 128;
-    const int bn = (tile % 10 == 2 || tile == 14) ? 160 : (tile % 10 == 3 ? 64 : 128);
+    const int bm = tile == 14 || tile % 10 == 5 ? 256 : 128;
+    const int bn = (tile % 10 == 2 || tile == 14) ? 160 : (tile % 10 == 3 ? 64 : 128);  // x1: 128, x2: 160, x3: 64
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (d->split_k == 0 && blocks < 384) {
@@ -655,6 +685,28 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 15:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
       return launch_glds<2, 4, 2, 2>(a, s);  // 128 x 256, 8 waves
+    // software-pipelined LDS fragment reads
+    case 31:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 2, 2, 2, 2, true>(a, s);
+    case 32:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 32 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 4, 5, 1, 2, true>(a, s);
+    case 33:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<1, 4, 2, 1, 2, true>(a, s);
+    case 25:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 4, 2, 2, 3, false>(a, s);  // 128 x 256, 8 waves, 3-stage ring
+    case 45:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 4, 2, 2, 3, true>(a, s);
+    case 41:
+      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
+      return launch_glds<2, 2, 2, 2, 3, true>(a, s);
+    case 42:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 42 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 4, 5, 1, 3, true>(a, s);
     // 3-stage ring, counted vmcnt (two K steps in flight)
     case 21:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
