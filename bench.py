@@ -178,10 +178,19 @@ def roofline_leg(job, steps):
     g = fam["gemm"]
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     total_ms = sum(v["ms"] for v in fam.values())
+    # HBM traffic of this kernel family comes from separate rocprofv3 --pmc passes (tools/pmc_bench.sh: FETCH_SIZE and
+    # WRITE_SIZE cannot share a pass; gfx950 FETCH_SIZE x2 correction applied); the committed summary is read back here
+    traffic, traffic_src = None, None
+    for rnd in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
+        f = os.path.join(REPO, "profiles", rnd, "pmc_gemm_traffic.json")
+        if os.path.exists(f):
+            traffic, traffic_src = json.load(open(f))["hbm_bytes_per_launch"], f"profiles/{rnd}/pmc_gemm_traffic.json"
+            break
     return {
         "bound": "mfma", "kernel": "gemm_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
         "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
-        "traffic": None,
+        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate run)", "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch_avg": None,
         "launches": int(g["launches"]), "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2),
         "flops_per_launch_avg": g["work"] / max(g["launches"], 1),
         "share_of_gpu_time": round(g["ms"] / total_ms, 4) if total_ms else None,

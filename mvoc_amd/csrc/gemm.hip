@@ -303,7 +303,7 @@ int launch(const GemmArgs& a0, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int WN, int WM, int TN, int TM, int NST, bool PF = false>
+template <int WN, int WM, int TN, int TM, int NST, int PF = 0>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
   constexpr int BKK = 64;
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
-    if constexpr (!PF) {
+    if constexpr (PF != 1) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int off = ((2 * s + h) ^ swz) * 16;
@@ -469,11 +469,13 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + off);
 #pragma unroll
         for (int j = 0; j < TM; ++j) af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + off);
+        if constexpr (PF == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        if constexpr (PF == 2) __builtin_amdgcn_s_setprio(0);
       }
     } else {
       // software-pipelined fragments: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <int WN, int WM, int TN, int TM, int NST = 2, bool PF = false>
+template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -688,25 +690,28 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     // software-pipelined LDS fragment reads
     case 31:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 2, 2, 2, 2, true>(a, s);
+      return launch_glds<2, 2, 2, 2, 2, 1>(a, s);
     case 32:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 32 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 2, true>(a, s);
+      return launch_glds<1, 4, 5, 1, 2, 1>(a, s);
     case 33:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<1, 4, 2, 1, 2, true>(a, s);
+      return launch_glds<1, 4, 2, 1, 2, 1>(a, s);
+    case 52:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 52 needs k, cin, c1 %% 64 == 0 and no GEGLU");
+      return launch_glds<1, 4, 5, 1, 2, 2>(a, s);  // 160 x 128 with s_setprio around the MFMA clusters
     case 25:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 4, 2, 2, 3, false>(a, s);  // 128 x 256, 8 waves, 3-stage ring
+      return launch_glds<2, 4, 2, 2, 3, 0>(a, s);  // 128 x 256, 8 waves, 3-stage ring
     case 45:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 4, 2, 2, 3, true>(a, s);
+      return launch_glds<2, 4, 2, 2, 3, 1>(a, s);
     case 41:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 2, 2, 2, 3, true>(a, s);
+      return launch_glds<2, 2, 2, 2, 3, 1>(a, s);
     case 42:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 42 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 3, true>(a, s);
+      return launch_glds<1, 4, 5, 1, 3, 1>(a, s);
     // 3-stage ring, counted vmcnt (two K steps in flight)
     case 21:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
