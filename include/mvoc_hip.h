@@ -65,6 +65,15 @@ typedef struct mvoc_gemm_desc {
   int32_t split_k;      /* 0 = auto, 1 = off, n = force n K-slices (needs workspace; direct-to-LDS tiles only) */
   void* workspace;      /* optional fp32 scratch for split-K partial slabs: split_k * m * n * 4 bytes */
   size_t workspace_bytes;
+  /* LayerNorm folded into the GEMM (F.layer_norm feeding F.linear at pnp_utils.py:250/296/322 -> :604-612, :335):
+   * `a` holds the RAW rows, `w` holds gamma-scaled weights W' = W * gamma; the kernel accumulates mean / rstd of every
+   * row from the tiles it stages anyway and the epilogue forms rstd*(acc - mean*ln_rowsum[n]) + ln_bias[n].
+   * ln_rowsum = sum_k W'[n,k], ln_bias = beta @ W^T + bias, both fp32 [n]; `bias` is ignored in this mode.  NULL = off. */
+  const void* ln_rowsum;
+  const void* ln_bias;
+  float ln_eps;
+  const void* ln_stats; /* optional {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (one read of the rows, shared by
+                           every n-tile); NULL: each block accumulates the statistics of its rows in the K loop */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
@@ -113,6 +122,10 @@ typedef struct mvoc_gn_desc {
 } mvoc_gn_desc;
 size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups);
 int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream);
+
+/* per-row {mean, rstd} (fp32 [rows][2]) of a [rows, c] fp16 matrix: the statistics half of F.layer_norm for GEMMs that
+ * fold the normalisation into their epilogue (mvoc_gemm_desc.ln_*) */
+int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream);
 
 /* LayerNorm over the last dim (F.layer_norm at pnp_utils.py:250,296,322), eps 1e-5, affine */
 int mvoc_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int64_t rows, int32_t c,

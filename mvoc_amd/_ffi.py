@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("rowadd_div", i32), ("a_mode", i32), ("lda", i32), ("lda2", i32), ("c1", i32), ("cin", i32),
                 ("nimg", i32), ("hout", i32), ("wout", i32), ("hsrc", i32), ("wsrc", i32), ("stride", i32),
                 ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
-                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz)]
+                ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("ln_rowsum", vp), ("ln_bias", vp),
+                ("ln_eps", f32), ("ln_stats", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
     "mvoc_layernorm_f16": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
+    "mvoc_row_stats_f16": (i32, [vp, vp, i64, i32, f32, vp]),
     "mvoc_pnp_blend_scatter_tokens": (i32, [C.POINTER(PnpDesc), vp]),
     "mvoc_pnp_blend_scatter_nchw": (i32, [C.POINTER(PnpDesc), vp]),
     "mvoc_ddim_step_f16": (i32, [vp, vp, vp, vp, vp, i64, vp]),

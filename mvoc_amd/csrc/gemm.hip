@@ -42,6 +42,10 @@ struct GemmArgs {
   int frames, hw;
   int act;
   int n_tiles, m_tiles;
+  const float* ln_s;   // LayerNorm folded into this GEMM: row sums of the gamma-scaled weights (fp32 [N]) or NULL
+  const float* ln_c;   //   beta @ W^T (+ bias), fp32 [N]
+  const float* ln_stats;  // optional precomputed {mean, rstd} per row (fp32 [M][2]); NULL: accumulated in the K loop
+  float ln_eps;
   int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
   float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
 };
@@ -54,7 +58,7 @@ struct RowInfo {   // per staged activation row (fixed for the whole K loop)
 
 template <int WN, int WM, int TN, int TM>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TN][TM], int n0, int m0, int wn, int wm,
-                                              int r, int h) {
+                                              int r, int h, const float* lnstat = nullptr) {
   // ---- epilogue: lane owns pixel m = tile_m + r and, per register quad q, channels n..n+3 ---------------
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -63,6 +67,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
     const half_t* ra = p.rowadd ? p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd : nullptr;
     const half_t* rs = p.resid ? p.resid + (size_t)m * p.ldr : nullptr;
     half_t* orow = p.out + (size_t)m * p.ldo;
+    // folded LayerNorm: the MFMAs multiplied the RAW rows by gamma-scaled weights; with mu/rstd of this row
+    //   LN(x) @ W^T + b  =  rstd * (acc - mu * rowsum(W')) + (beta @ W^T + b)      (applied per quad below)
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (lnstat) {
+      ln_mu = lnstat[2 * ((wm * TM + j) * 32 + r)];
+      ln_rs = lnstat[2 * ((wm * TM + j) * 32 + r) + 1];
+    }
+    const bool use_bias = p.bias && !lnstat;
     if (p.act == MVOC_ACT_GEGLU) {
       if constexpr (TN % 2 == 0) {
 #pragma unroll
@@ -73,15 +85,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
             if (nh >= p.N) continue;
             const int no = (n0 + (wn * TN + i) * 32) / 2 + 8 * q + 4 * h;
             half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-            if (p.bias) {
+            if (use_bias) {
               bh = *reinterpret_cast<const half4_t*>(p.bias + nh);
               bg = *reinterpret_cast<const half4_t*>(p.bias + nh + 32);
+            }
+            f32x4 sh = {0.f, 0.f, 0.f, 0.f}, sg = sh, ch = sh, cg = sh;
+            if (lnstat) {
+              sh = *reinterpret_cast<const f32x4*>(p.ln_s + nh);
+              sg = *reinterpret_cast<const f32x4*>(p.ln_s + nh + 32);
+              ch = *reinterpret_cast<const f32x4*>(p.ln_c + nh);
+              cg = *reinterpret_cast<const f32x4*>(p.ln_c + nh + 32);
             }
             half4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float hv = r16(acc[i][j][q * 4 + e] + (float)bh[e]);
-              const float gv = r16(acc[i + 1][j][q * 4 + e] + (float)bg[e]);
+              const float hv = r16(lnstat ? ln_rs * (acc[i][j][q * 4 + e] - ln_mu * sh[e]) + ch[e] : acc[i][j][q * 4 + e] + (float)bh[e]);
+              const float gv = r16(lnstat ? ln_rs * (acc[i + 1][j][q * 4 + e] - ln_mu * sg[e]) + cg[e]
+                                          : acc[i + 1][j][q * 4 + e] + (float)bg[e]);
               float v = r16(hv * r16(gelu_fast_f(gv)));
               if (rs) v = r16(v + (float)rs[no + e]);
               o[e] = (half_t)v;
@@ -98,10 +118,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
           const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
           if (n >= p.n_store) continue;
           half4_t b4 = {0, 0, 0, 0};
-          if (p.bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
+          if (use_bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
           float v[4];
+          if (lnstat) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.ln_c + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
+            for (int e = 0; e < 4; ++e) v[e] = r16(ln_rs * (acc[i][j][q * 4 + e] - ln_mu * s4[e]) + c4[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
+          }
           if (ra) {
             const half4_t t4 = *reinterpret_cast<const half4_t*>(ra + n);
 #pragma unroll
@@ -439,6 +466,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
 
   const int nk = p.k_per_split / BKK;
   const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
+  float ln_s1 = 0.f, ln_s2 = 0.f;
+  static_assert(WN * WM * 64 == 2 * BM, "LayerNorm folding assumes two threads per staged activation row");
   issue(0);
   if (NST == 3 && nk > 1) issue(1);
   int cur = 0;
@@ -460,6 +489,22 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
+    if (p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
+      const int srow = tid >> 1;
+      const char* rp = smem + cur * STAGE + BN * ROW + srow * ROW;
+      const int rsw = (srow >> 1) & 7;
+      const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(rp + (((tid & 1) * 4 + c4) ^ rsw) * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2_t v2 = {v[2 * e], v[2 * e + 1]};
+          ln_s1 = __builtin_amdgcn_fdot2(v2, one2, ln_s1, false);
+          ln_s2 = __builtin_amdgcn_fdot2(v2, v2, ln_s2, false);
+        }
+      }
+    }
     if constexpr (PF != 1) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -523,6 +568,25 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
           *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = v;
         }
     }
+    return;
+  }
+  if (p.ln_s && p.ln_stats) {
+    gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, p.ln_stats + 2 * (size_t)m0);
+    return;
+  }
+  if (p.ln_s) {
+    ln_s1 += __shfl_xor(ln_s1, 1);
+    ln_s2 += __shfl_xor(ln_s2, 1);
+    const float mu = ln_s1 / (float)p.K;
+    const float var = fmaxf(ln_s2 / (float)p.K - mu * mu, 0.f);
+    __syncthreads();  // every wave is done with the staging buffers: reuse their first bytes for the row statistics
+    float* lnstat = reinterpret_cast<float*>(smem);
+    if ((tid & 1) == 0) {
+      lnstat[2 * (tid >> 1)] = mu;
+      lnstat[2 * (tid >> 1) + 1] = rsqrtf(var + p.ln_eps);
+    }
+    __syncthreads();
+    gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, lnstat);
     return;
   }
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
@@ -613,6 +677,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   a.ups_sw = d->upsample ? (float)d->wsrc / (float)d->wup : 1.f;
   a.frames = d->frames; a.hw = d->hw; a.act = d->act;
   a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
+  a.ln_s = (const float*)d->ln_rowsum; a.ln_c = (const float*)d->ln_bias; a.ln_eps = d->ln_eps;
+  a.ln_stats = (const float*)d->ln_stats;
   if (d->a_mode == MVOC_A_CONV3X3) {
     MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
     MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");
@@ -632,6 +698,11 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   MvocProfScope prof(MVOC_FAM_GEMM, s, flops);
   const bool glds_ok = d->k % 64 == 0 && d->cin % 64 == 0 && d->c1 % 64 == 0 &&
                        (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin);
+  if (d->ln_rowsum) {
+    MVOC_REQUIRE(d->ln_bias && glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && d->split_k <= 1 &&
+                     (d->tile == 0 || d->tile >= 11),
+                 -2, "gemm: LayerNorm folding needs the plain single-source direct-to-LDS path (k %% 64 == 0), no split-K");
+  }
   int tile = d->tile;
   if (tile == 0 && glds_ok) {  // measured per shape on MI355X (tools/gemm_bench.py)
     if (d->act == MVOC_ACT_GEGLU) tile = d->m >= 8192 ? 15 : 11;
@@ -647,7 +718,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     else if (d->n % 128 == 0 && d->m >= 2048) tile = 1;
     else tile = 3;
   }
-  if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1) {
+  if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
     const int bm = tile == 14 || tile % 10 == 5 ? 256 : 128;
     const int bn = (tile % 10 == 2 || tile == 14) ? 160 : (tile % 10 == 3 ? 64 : 128);  // x1: 128, x2: 160, x3: 64

@@ -234,7 +234,48 @@ __global__ __launch_bounds__(256) void ln_kernel(const half_t* __restrict__ x, c
   }
 }
 
+// per-row mean / rstd only (LayerNorm folded into the consumer GEMM): one wave per row, 16-byte loads
+__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, float* __restrict__ stats, long rows,
+                                                        int c, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nch = c / 8;
+  const half_t* xr = x + row * c;
+  const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+  float s1 = 0.f, s2 = 0.f;
+  for (int cc = lane; cc < nch; cc += 64) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(xr + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const half2_t v2 = {v[2 * e], v[2 * e + 1]};
+      s1 = __builtin_amdgcn_fdot2(v2, one2, s1, false);
+      s2 = __builtin_amdgcn_fdot2(v2, v2, s2, false);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane == 0) {
+    const float mu = s1 / c;
+    stats[2 * row] = mu;
+    stats[2 * row + 1] = rsqrtf(fmaxf(s2 / c - mu * mu, 0.f) + eps);
+  }
+}
+
 }  // namespace
+
+extern "C" int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream) {
+  MVOC_REQUIRE(x && stats && rows > 0 && c >= 8 && c % 8 == 0, -1, "row_stats: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_LN, s, 2.0 * (double)rows * c);
+  const long nblk = (rows + 3) / 4;
+  MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "row_stats: too many rows");
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const half_t*)x, (float*)stats, (long)rows, c, eps);
+  return mvoc_check_launch("row_stats_kernel");
+}
 
 extern "C" size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups) {
   GnArgs a;

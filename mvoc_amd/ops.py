@@ -72,8 +72,9 @@ def _out_cols(w, n_store, act):
 
 
 def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0,
-           split_k=0):
-    """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T)."""
+           split_k=0, ln=None):
+    """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T).
+    ``ln=(rowsum fp32 [n], lnbias fp32 [n], eps)``: LayerNorm(x) folded into the GEMM (w must be gamma-scaled)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
     _rowmajor(x, "x")
     m = x.shape[0]
@@ -91,6 +92,12 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
     d.c1 = k1
     d.cin = k1 + k2
     d.split_k = split_k
+    if ln is not None:
+        rowsum, lnbias, eps = ln[:3]
+        _chk(rowsum, "ln rowsum", torch.float32), _chk(lnbias, "ln bias", torch.float32)
+        d.ln_rowsum, d.ln_bias, d.ln_eps, d.split_k = rowsum.data_ptr(), lnbias.data_ptr(), eps, 1
+        if len(ln) > 3 and ln[3] is not None:
+            d.ln_stats = _chk(ln[3], "ln stats", torch.float32).data_ptr()
     _gemm(d, x.device)
     return out
 
@@ -188,6 +195,16 @@ def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.nsample, d.rows_per_sample, d.c, d.c1, d.groups, d.silu, d.eps = nsample, rows_per_sample, c, c1, groups, int(silu), eps
     check(lib.mvoc_groupnorm_f16(C.byref(d), _stream()), "groupnorm")
+    return out
+
+
+def row_stats(x, eps=1e-5):
+    """{mean, rstd} per row, fp32 [rows, 2]"""
+    _chk(x, "x")
+    if not x.is_contiguous():
+        raise RuntimeError("row_stats: x must be contiguous")
+    out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    check(lib.mvoc_row_stats_f16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], eps, _stream()), "row_stats")
     return out
 
 

@@ -107,9 +107,32 @@ class Linear:
         if b is not None:
             self.b = torch.zeros(self.w.shape[0], dtype=H16, device=w.device)
             self.b[:self.n] = b.to(H16)
+        self.ln = None
 
     def __call__(self, x, **kw):
         return ops.linear(x, self.w, self.b, n_store=self.n, **kw)
+
+    def fold_layernorm(self, gamma, beta, eps=1e-5):
+        """LayerNorm(x) @ W^T + b  ==  rstd * (x @ (W*gamma)^T - mean * rowsum(W*gamma)) + (beta @ W^T + b): the GEMM
+        reads the raw rows, accumulates their mean / rstd from the tiles it stages anyway (csrc/gemm.hip) and the
+        LayerNorm kernel, its output tensor and one HBM round trip disappear."""
+        if self.w.shape[1] % 64:
+            return self  # the folded path needs the direct-to-LDS GEMM (K % 64 == 0); keep the explicit LayerNorm
+        w32 = self.w.float()
+        wg = (w32 * gamma.float()[None, :]).to(H16)
+        c = w32 @ beta.float()
+        if self.b is not None:
+            c = c + self.b.float()
+        self.w_ln = wg.contiguous()
+        self.ln = (wg.float().sum(dim=1).contiguous(), c.contiguous(), float(eps))
+        return self
+
+    def call_ln(self, x, norm, **kw):
+        """x: raw rows; norm = (gamma, beta) of the LayerNorm that precedes this linear"""
+        if self.ln is None:
+            return self(ops.layernorm(x, *norm), **kw)
+        stats = ops.row_stats(x, self.ln[2])  # one read of the rows; every n-tile of the GEMM shares it
+        return ops.linear(x, self.w_ln, None, n_store=self.n, ln=self.ln + (stats,), **kw)
 
 
 class Attention:
@@ -136,9 +159,11 @@ class BasicTransformerBlock:
         self.attn1 = Attention(sd, prefix + ".attn1", heads, False)
         self.attn2 = Attention(sd, prefix + ".attn2", heads, cross)
         w, b = pack_geglu(g(".ff.net.0.proj.weight"), g(".ff.net.0.proj.bias"))
-        self.ff1_w, self.ff1_b = w, b
+        self.ff1 = Linear(w, b).fold_layernorm(*self.norm3)
         self.ff2 = Linear(g(".ff.net.2.weight"), g(".ff.net.2.bias"))
         self.dim = dim
+        self.attn1.to_qkv.fold_layernorm(*self.norm1)
+        (self.attn2.to_q if cross else self.attn2.to_qkv).fold_layernorm(*self.norm2)
 
 
 class _TransformerBase:
@@ -168,8 +193,7 @@ class Transformer2DModel(_TransformerBase):
         h = self.proj_in(h)
         c = blk.dim
         # self-attention over the H*W tokens of each image
-        n = ops.layernorm(h, *blk.norm1)
-        qkv = blk.attn1.to_qkv(n)
+        qkv = blk.attn1.to_qkv.call_ln(h, blk.norm1)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         proc = blk.attn1.processor
         if proc.injecting():
@@ -181,14 +205,12 @@ class Transformer2DModel(_TransformerBase):
         a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
         h = blk.attn1.to_out(a, resid=h)
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
-        n = ops.layernorm(h, *blk.norm2)
-        q2 = blk.attn2.to_q(n)
+        q2 = blk.attn2.to_q.call_ln(h, blk.norm2)
         kv = blk.attn2.to_kv(ctx.tokens)
         a = ops.flash_attn(q2, kv[:, :c], kv[:, c:], nbatch=nimg, heads=self.heads, tq=hw, tk=ctx.length,
                            kv_bdiv=ctx.frames_per_ctx)
         h = blk.attn2.to_out(a, resid=h)
-        n = ops.layernorm(h, *blk.norm3)
-        f1 = ops.linear(n, blk.ff1_w, blk.ff1_b, act=ACT_GEGLU)
+        f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
         return self.proj_out(h, resid=x)
 
@@ -208,8 +230,7 @@ class TransformerTemporalModel(_TransformerBase):
         h = self.proj_in(h)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
-            n = ops.layernorm(h, *norm)
-            qkv = attn.to_qkv(n)
+            qkv = attn.to_qkv.call_ln(h, norm)
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
             proc = attn.processor
             if attn is blk.attn1 and proc.injecting():
@@ -220,8 +241,7 @@ class TransformerTemporalModel(_TransformerBase):
                                      f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
             a = ops.temporal_attn(q, k, v, nsample=B, frames=F, hw=hw, heads=self.heads)
             h = attn.to_out(a, resid=h)
-        n = ops.layernorm(h, *blk.norm3)
-        f1 = ops.linear(n, blk.ff1_w, blk.ff1_b, act=ACT_GEGLU)
+        f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
         return self.proj_out(h, resid=x)
 

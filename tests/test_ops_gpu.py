@@ -96,6 +96,36 @@ def test_split_k(ops, split_k):
     assert rel_l2(ot.reshape(nb, frames, hw, cc).permute(0, 3, 1, 2)[..., None], reft) < 1.5e-3
 
 
+@pytest.mark.parametrize("c,n,geglu", [(320, 960, False), (64, 192, False), (1280, 1280, False), (128, 1024, True), (640, 5120, True)])
+def test_linear_layernorm_fold(ops, c, n, geglu):
+    """LayerNorm folded into the GEMM (row statistics accumulated in the K loop) vs F.layer_norm -> F.linear"""
+    from mvoc_amd.unet import Linear, pack_geglu
+    g = torch.Generator().manual_seed(c + n)
+    m = 1000
+    x = (torch.randn(m, c, generator=g) * 1.7 + 0.6).half()
+    x[3] = x[3] * 8 + 5  # a row with a large mean: the mean*rowsum cancellation must hold up
+    w = (torch.randn(n, c, generator=g) / math.sqrt(c)).half()
+    b = torch.randn(n, generator=g).half()
+    gm, bt = (1 + 0.3 * torch.randn(c, generator=g)).half(), (0.3 * torch.randn(c, generator=g)).half()
+    y = F.layer_norm(x.float(), (c,), gm.float(), bt.float(), 1e-5).half().float() @ w.float().t() + b.float()
+    if geglu:
+        hh, gg = y.half().float().chunk(2, dim=-1)
+        ref = hh * F.gelu(gg)
+        wp, bp = pack_geglu(dev(w), dev(b))
+        lin = Linear(wp, bp).fold_layernorm(dev(gm), dev(bt))
+        out = lin.call_ln(dev(x), (dev(gm), dev(bt)), act=ops.ACT_GEGLU)
+    else:
+        ref = y
+        lin = Linear(dev(w), dev(b)).fold_layernorm(dev(gm), dev(bt))
+        out = lin.call_ln(dev(x), (dev(gm), dev(bt)))
+    assert lin.ln is not None
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 3e-2 * ref.abs().max()
+    # the in-kernel statistics path (no precomputed stats) must agree
+    out2 = ops.linear(dev(x), lin.w_ln, None, n_store=lin.n, ln=lin.ln, act=ops.ACT_GEGLU if geglu else ops.ACT_NONE)
+    assert rel_l2(out2, out) < 1e-3
+
+
 def test_linear_concat_and_acts(ops):
     g = torch.Generator().manual_seed(5)
     m, k1, k2, n = 300, 128, 64, 192
