@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvoc_hip.so")
+LIB_PATH = os.environ.get("MVOC_HIP_LIB") or os.path.join(_HERE, "libmvoc_hip.so")  # override: A/B builds
 
 A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU = 0, 1, 2, 3

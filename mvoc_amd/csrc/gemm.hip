@@ -301,6 +301,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(const GemmArgs p) {
   }
 
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
+#undef MVOC_SWZ
 }
 
 template <int WN, int WM, int TN, int TM>
@@ -330,10 +331,14 @@ int launch(const GemmArgs& a0, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int WN, int WM, int TN, int TM, int NST, int PF = 0>
+template <int WN, int WM, int TN, int TM, int NST, int PF = 0, int BKK = 64>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
-  constexpr int BKK = 64;
+  static_assert(BKK == 64 || BKK == 32, "K step of 64 (128-byte staged rows) or 32 (64-byte rows)");
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
+  constexpr int RPI = 64 / NCH;          // rows one LDS-DMA wave-instruction covers
+  // XOR swizzle of the chunk position: 128-byte rows -> (row >> 1) & 7, 64-byte rows -> (row >> 2) & 3; either way
+  // 16 consecutive rows reading the same logical chunk touch 16 distinct 16-byte slots of a 256-byte bank window
+#define MVOC_SWZ(row) (BKK == 64 ? (((row) >> 1) & 7) : (((row) >> 2) & 3))
   constexpr int NW = WN * WM;            // waves
   constexpr int BN = WN * TN * 32;
   constexpr int BM = WM * TM * 32;
@@ -362,14 +367,14 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   const half_t* zsrc = reinterpret_cast<const half_t*>(&g_zero16);
 
   // lane -> (row within the 8-row group of an instruction, position); source chunk = pos ^ swizzle(row)
-  const int lrow = lane >> 3, pos = lane & 7;
+  const int lrow = lane / NCH, pos = lane % NCH;
   // ---- weight side: instruction j = wave + i*NW covers rows j*8 .. j*8+7 -------------------------------
   const half_t* wsrc[PW];
   bool wok[PW];
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
-    const int row = (wave + i * NW) * 8 + lrow;
-    const int c = pos ^ ((row >> 1) & 7);
+    const int row = (wave + i * NW) * RPI + lrow;
+    const int c = pos ^ MVOC_SWZ(row);
     wok[i] = row < BN && n0 + row < p.N;
     wsrc[i] = p.w + (size_t)(wok[i] ? n0 + row : 0) * p.K + c * 8;
   }
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   int ry0[PA], rx0[PA], rimg[PA];  // only the upsample path still needs coordinates
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int row = (wave + i * NW) * 8 + lrow;
+    const int row = (wave + i * NW) * RPI + lrow;
     const int m = m0 + row;
     const bool live = m < p.M;
     const int mm = live ? m : 0;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         if (live && f + t - 1 >= 0 && f + t - 1 < p.frames) mk |= 1u << t;
       vmask[i] = mk;
     }
-    cch[i] = (pos ^ ((row >> 1) & 7)) * 8;
+    cch[i] = (pos ^ MVOC_SWZ(row)) * 8;
   }
   int tap = kbeg / p.cin, ch0 = kbeg - tap * p.cin;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
   // weight pointers advance by one K step per issue; rows beyond N read the zero constant with stride 0
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = p.k_per_split / BKK;
-  const int swz = (r >> 1) & 7;  // tile bases are multiples of 32 rows: the swizzle depends on r only
+  const int swz = MVOC_SWZ(r);  // tile bases are multiples of 32 rows: the swizzle depends on r only
   float ln_s1 = 0.f, ln_s2 = 0.f;
   static_assert(WN * WM * 64 == 2 * BM, "LayerNorm folding assumes two threads per staged activation row");
   issue(0);
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
-    if (p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
+    if (BKK == 64 && p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
       const int srow = tid >> 1;
       const char* rp = smem + cur * STAGE + BN * ROW + srow * ROW;
       const int rsw = (srow >> 1) & 7;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     if constexpr (PF != 1) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < BKK / 16; ++s) {
         const int off = ((2 * s + h) ^ swz) * 16;
         half8_t wf[TN], af[TM];
 #pragma unroll
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         if constexpr (PF == 2) __builtin_amdgcn_s_setprio(0);
       }
     } else {
+      static_assert(PF != 1 || BKK == 64, "the fragment-prefetch variant is written for K step 64");
       // software-pipelined fragments: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s
       half8_t wf[2][TN], af[2][TM];
       {
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0>
+template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0, int BKK = 64>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -640,7 +646,7 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
   if (a.split_k > 1) {
     const long nthr = (long)a.M * (a.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -768,6 +774,17 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 33:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
       return launch_glds<1, 4, 2, 1, 2, 1>(a, s);
+    // K step 32: half the LDS per block -> more resident blocks per CU
+    case 61:
+      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 61 needs k, cin, c1 %% 64 == 0 and row statistics");
+      return launch_glds<2, 2, 2, 2, 2, 0, 32>(a, s);
+    case 62:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
+                   "gemm: tile 62 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
+      return launch_glds<1, 4, 5, 1, 2, 0, 32>(a, s);
+    case 63:
+      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 63 needs k, cin, c1 %% 64 == 0 and row statistics");
+      return launch_glds<1, 4, 2, 1, 2, 0, 32>(a, s);
     case 52:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 52 needs k, cin, c1 %% 64 == 0 and no GEGLU");
       return launch_glds<1, 4, 5, 1, 2, 2>(a, s);  // 160 x 128 with s_setprio around the MFMA clusters
