@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mix", default="job", choices=["job", "inv", "comp"],
                     help="diagnostics: time only inversion (B=1) or only composition (B=5) steps; the metric is --mix job")
+    ap.add_argument("--workload", default="boat_surf", choices=["boat_surf", "longclip"],
+                    help="boat_surf = the metric (BASELINE configs[1], per-object shards across GPUs, weak scaling); longclip = "
+                         "BASELINE configs[3]: ONE 32-frame 768x768 clip, frame axis sharded over the GPUs (strong scaling)")
+    ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="longclip: frame<->pixel exchange form")
     return ap.parse_args()
 
 
@@ -243,6 +247,76 @@ def cpu_baseline(frames, latent):
     }
 
 
+def longclip(args, rank, world, device, dist):
+    """BASELINE configs[3]: DDIM inversion steps of one long clip, frame-sharded (mvoc_amd/frame_shard.py).  Extra
+    diagnostic line, not the metric: strong scaling, value = steps/s of the ONE clip."""
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    from mvoc_amd.flops import unet_flops
+    frames = args.frames if args.frames != 16 else 32
+    latent = args.latent if args.latent != 64 else 96
+    # eager when sharded: the RCCL exchanges are issued by torch.distributed between the library's launches
+    pipe = I2VGenXLPipeline.synthetic(device=device, seed=8888, use_graphs=(world == 1 and not args.no_graphs))
+    shard = None
+    if world > 1:
+        from mvoc_amd.frame_shard import FrameShard
+        shard = FrameShard(exchange=args.exchange)
+        pipe.unet.set_frame_shard(shard)
+    sched = DDIMInverseScheduler()
+    sched.set_timesteps(50)
+    pipe.scheduler = sched
+    pipe._guidance_scale = 1.0
+    H = W = latent * 8
+    cond = pipe._stock_conditioning("", "", "first-frame", frames, H, W, 8, None, None, None, None)
+    g = torch.Generator().manual_seed(8888)
+    lat = torch.randn((1, 4, frames, latent, latent), generator=g).to(device, torch.float16)
+    st = pipe._make_stock_step("longclip", lat, cond, 1.0)
+    table, index = sched.coef_table(device, 1.0)
+
+    def step(i):
+        t = int(sched.timesteps[i % 50])
+        st["t"].fill_(float(t))
+        st["coef"].copy_(table[index[t]])
+        st["run"]()
+
+    for i in range(max(args.warmup, 2)):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if shard is not None:
+        shard.bytes_sent = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fl = unet_flops(pipe.unet.config, 1, frames, latent, latent)["total"]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "UNet3D denoising steps/sec, one long clip, frame-axis shard", "value": round(args.steps / dt, 4),
+            "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"DDIM inversion of ONE clip, {frames} frames x {H}x{W}, UNet batch 1, frame axis sharded "
+                                   f"{frames // world} frames per GPU, temporal sections pixel-sharded ({args.exchange})",
+                       "frames": frames, "height": H, "width": W, "exchange": args.exchange if world > 1 else None,
+                       "tflop_per_step": round(fl / 1e12, 2), "end_to_end_tflops": round(fl * args.steps / dt / 1e12, 2),
+                       "exchange_payload_mb_per_rank_per_step": None if shard is None else round(shard.bytes_sent / args.steps / 1e6, 1),
+                       "hip_graphs": world == 1 and not args.no_graphs}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -257,8 +331,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max-reduce only
+        dist.init_process_group("nccl", device_id=device)  # RCCL; the metric workload uses it for barrier + max-reduce only
 
+    if args.workload == "longclip":
+        return longclip(args, rank, world, device, dist)
     job = Job(device, args.frames, args.latent, not args.no_graphs)
     job.mix = args.mix
     # prime every graph variant the timed region will replay, then W untimed warm-up steps

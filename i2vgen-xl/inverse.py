@@ -55,8 +55,10 @@ def build_pipeline(device, synthetic):
     return I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=torch.float16, variant="fp16", device=device)
 
 
-def main(template_config, configs_list, device, synthetic=False):
+def main(template_config, configs_list, device, synthetic=False, frame_shard=None):
     pipe = build_pipeline(device, synthetic)
+    if frame_shard is not None:
+        pipe.enable_frame_shard(frame_shard)
     g = torch.Generator().manual_seed(template_config.seed)
     inverse_scheduler = DDIMInverseScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
     ddim_scheduler = DDIMScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
@@ -100,6 +102,9 @@ if __name__ == "__main__":
     ap.add_argument("--configs_json", type=str, default="configs/group_inversion/group_config.json")
     ap.add_argument("--synthetic", action="store_true", help="seeded synthetic UNet weights + conditioning (no checkpoint)")
     ap.add_argument("--shard", type=str, default=None, help="i/n: process entry k when k %% n == i")
+    ap.add_argument("--frame_shard", action="store_true",
+                    help="under torchrun: every rank works on the SAME entries, each clip's frame axis sharded over the ranks "
+                         "(RCCL; for clips too long for one GPU's latency budget) instead of one entry per rank")
     args = ap.parse_args()
     template_config = OmegaConf.load(args.template_config)
     logging.basicConfig(level=logging.DEBUG if template_config.debug else logging.INFO,
@@ -110,4 +115,13 @@ if __name__ == "__main__":
     device = pick_device(template_config.device, args.shard)
     torch.set_grad_enabled(False)
     seed_everything(template_config.seed)
-    main(template_config, my_entries(configs_list, args.shard), device, args.synthetic)
+    if args.frame_shard and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        from mvoc_amd.frame_shard import FrameShard
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=device)
+        main(template_config, configs_list, device, args.synthetic, frame_shard=FrameShard())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        main(template_config, my_entries(configs_list, args.shard), device, args.synthetic)

@@ -123,6 +123,16 @@ typedef struct mvoc_gn_desc {
 size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups);
 int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream);
 
+/* The same GroupNorm in two halves, for a sample whose rows are spread over several GPUs (frame-axis shard of one
+ * long clip, SURVEY 8e / BASELINE configs[3]: the 5-D norms at pnp_utils.py:185-188 and inside TemporalConvLayer,
+ * pnp_utils.py:1048-1051, take their statistics over ALL frames and pixels):
+ *   moments : this rank's rows -> moments [nsample][groups][3] fp32 {count, mean, M2}   (gamma/beta/out unused)
+ *   exchange: the caller all-gathers the triples (RCCL; 12*nsample*groups bytes per rank) -> parts [nparts][nsample][groups][3]
+ *   apply   : Chan-combines the parts in index order (every rank gets bit-identical mean/rstd) and normalises this rank's rows.
+ * With nparts == 1 the pair reproduces mvoc_groupnorm_f16 bit for bit. */
+int mvoc_groupnorm_moments_f16(const mvoc_gn_desc* d, void* moments, void* stream);
+int mvoc_groupnorm_apply_moments_f16(const mvoc_gn_desc* d, const void* parts, int32_t nparts, void* stream);
+
 /* per-row {mean, rstd} (fp32 [rows][2]) of a [rows, c] fp16 matrix: the statistics half of F.layer_norm for GEMMs that
  * fold the normalisation into their epilogue (mvoc_gemm_desc.ln_*) */
 int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream);

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
+    "mvoc_groupnorm_moments_f16": (i32, [C.POINTER(GnDesc), vp, vp]),
+    "mvoc_groupnorm_apply_moments_f16": (i32, [C.POINTER(GnDesc), vp, i32, vp]),
     "mvoc_layernorm_f16": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
     "mvoc_row_stats_f16": (i32, [vp, vp, i64, i32, f32, vp]),
     "mvoc_pnp_blend_scatter_tokens": (i32, [C.POINTER(PnpDesc), vp]),

@@ -19,6 +19,7 @@ struct GnArgs {
   const half_t* beta;
   half_t* out;
   float* ws;  // [nsample][nchunk][G][3] partials, then [nsample][G][2] finals
+  float* mom_out;  // when set, gn_final writes the sample's raw (count, mean, M2) here instead of (mean, rstd)
   int nsample, R, c, c1, c2, G, cpg, silu;
   int nchunk, rows_per_chunk;
   int CW, RY, npass;
@@ -125,10 +126,31 @@ __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
     __syncthreads();
   }
   if (lane == 0) {
+    if (p.mom_out) {
+      float* mo = p.mom_out + ((long)smp * p.G + g) * 3;
+      mo[0] = acc.n; mo[1] = acc.mean; mo[2] = acc.m2;
+      return;
+    }
     float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + ((long)smp * p.G + g) * 2;
     fin[0] = acc.mean;
     fin[1] = rsqrtf(acc.m2 / acc.n + p.eps);
   }
+}
+
+// Statistics of a sample that is spread over several devices (pixel- or frame-sharded 5-D GroupNorm): every rank
+// contributes one (count, mean, M2) triple per (sample, group); they are Chan-combined in rank order, so every rank
+// derives bit-identical (mean, rstd).
+__global__ __launch_bounds__(256) void gn_merge_parts(const float* __restrict__ parts, int nparts, int ng, float eps,
+                                                      float* __restrict__ fin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ng) return;
+  GnMoments acc = {0.f, 0.f, 0.f};
+  for (int r = 0; r < nparts; ++r) {
+    const float* in = parts + ((long)r * ng + i) * 3;
+    gn_merge(acc, in[0], in[1], in[2]);
+  }
+  fin[i * 2] = acc.mean;
+  fin[i * 2 + 1] = rsqrtf(acc.m2 / acc.n + eps);
 }
 
 __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
@@ -286,15 +308,16 @@ extern "C" size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_p
   return ((size_t)nsample * a.nchunk * groups * 3 + (size_t)nsample * groups * 2) * sizeof(float);
 }
 
-extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
-  MVOC_REQUIRE(d && d->x && d->gamma && d->beta && d->out && d->workspace, -1, "groupnorm: null operand");
+namespace {
+// shared argument validation of the three GroupNorm entry points; fills a (geometry included)
+int gn_setup(const mvoc_gn_desc* d, bool need_affine, GnArgs& a) {
+  MVOC_REQUIRE(d && d->x && d->workspace && (!need_affine || (d->gamma && d->beta && d->out)), -1, "groupnorm: null operand");
   MVOC_REQUIRE(d->nsample > 0 && d->rows_per_sample > 0, -1, "groupnorm: empty problem");
   MVOC_REQUIRE(d->c % 8 == 0 && d->c1 % 8 == 0 && d->c <= 2560 && d->groups > 0 && d->groups <= 256 &&
                    d->c % d->groups == 0,
                -2, "groupnorm: unsupported channels %d (c1 %d) / groups %d", d->c, d->c1, d->groups);
   MVOC_REQUIRE(d->x2 || d->c1 == d->c, -1, "groupnorm: c1 < c needs a second source");
   MVOC_REQUIRE(d->nsample <= 65535, -2, "groupnorm: too many samples");
-  GnArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const half_t*)d->x; a.x2 = (const half_t*)d->x2; a.gamma = (const half_t*)d->gamma;
   a.beta = (const half_t*)d->beta; a.out = (half_t*)d->out; a.ws = (float*)d->workspace;
@@ -303,6 +326,38 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
   gn_geometry(a);
   const size_t need = mvoc_groupnorm_workspace_bytes(d->nsample, d->rows_per_sample, d->c, d->groups);
   MVOC_REQUIRE(d->workspace_bytes >= need, -1, "groupnorm: workspace %zu < %zu bytes", d->workspace_bytes, need);
+  return 0;
+}
+}  // namespace
+
+extern "C" int mvoc_groupnorm_moments_f16(const mvoc_gn_desc* d, void* moments, void* stream) {
+  GnArgs a;
+  if (int rc = gn_setup(d, false, a)) return rc;
+  MVOC_REQUIRE(moments, -1, "groupnorm_moments: null output");
+  a.mom_out = (float*)moments;
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
+  hipLaunchKernelGGL(gn_partial, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(1024), 0, s, a);
+  return mvoc_check_launch("groupnorm_moments");
+}
+
+extern "C" int mvoc_groupnorm_apply_moments_f16(const mvoc_gn_desc* d, const void* parts, int32_t nparts, void* stream) {
+  GnArgs a;
+  if (int rc = gn_setup(d, true, a)) return rc;
+  MVOC_REQUIRE(parts && nparts > 0, -1, "groupnorm_apply_moments: no statistics");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
+  const int ng = a.nsample * a.G;
+  float* fin = a.ws + (long)a.nsample * a.nchunk * a.G * 3;
+  hipLaunchKernelGGL(gn_merge_parts, dim3((ng + 255) / 256), dim3(256), 0, s, (const float*)parts, nparts, ng, a.eps, fin);
+  hipLaunchKernelGGL(gn_apply, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
+  return mvoc_check_launch("groupnorm_apply_moments");
+}
+
+extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
+  GnArgs a;
+  if (int rc = gn_setup(d, true, a)) return rc;
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: read x once for stats + once for apply is the implementation; compulsory = read + write
   MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);

@@ -1,0 +1,107 @@
+"""Frame-axis shard of ONE long clip over the GPUs of a node (BASELINE configs[3]: 32 frames at 768x768
+on 8 GPUs -> 4 frames per rank).
+
+What is per-frame in the I2VGen-XL UNet runs unchanged on the rank's frames: resnets and their 4-D GroupNorms, spatial
+self- and cross-attention, up/down-sampling, conv_in / conv_out, every LayerNorm and feed-forward, the spatial Q/K and
+feature injections.  Three things cross frames (``pnp_utils.py:170-220``, ``:720-887``, ``:1042-1057``,
+``pipeline_i2vgen_xl.py:271-290``): temporal attention (all F frames of K/V per pixel), the temporal conv stacks
+(+-1 frame per conv, four chained) and the 5-D GroupNorms in front of both (statistics over all frames).  All three are
+point-wise in (h, w), so each *temporal section* runs PIXEL-sharded instead:
+
+    frame shard  [B, F/N, HW,   C]  --exchange-->  pixel shard [B, F, HW/N, C]  -- temporal section --  exchange back
+
+One exchange moves (N-1)/N of the rank's rows once; every kernel of the section (GroupNorm apply, K=3 frame conv,
+QKV / out projections, frame attention, GEGLU feed-forward) then sees all F frames of its pixels and needs no halo or
+K/V gather.  The only other collective is the 12 x B x groups-byte all-gather of GroupNorm moments.
+
+``exchange``:
+  * ``"a2a"``       RCCL all-to-all (default): each rank sends 1/N of its rows to every peer -- on the xGMI mesh every
+                    pair of GPUs has its own link, so all seven transfers of a rank proceed concurrently.
+  * ``"allgather"`` RCCL all-gather of the whole tensor, then each rank keeps its pixel slab (the form BASELINE.json
+                    names for temporal attention).  N x the bytes of ``a2a``; kept for comparison on the 8-GPU node.
+With the ``gloo`` backend (CPU tests, or two test processes sharing one GPU) the same calls are staged through host
+memory and the all-to-all is emulated by an all-gather; results are identical by construction.
+
+Pure torch + torch.distributed (no HIP kernels): the exchanges are importable and testable on a CPU-only machine.
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["FrameShard"]
+
+
+class FrameShard:
+    def __init__(self, group=None, exchange="a2a"):
+        if not dist.is_initialized():
+            raise RuntimeError("FrameShard: torch.distributed is not initialised (launch one process per GPU)")
+        if exchange not in ("a2a", "allgather"):
+            raise ValueError(f"FrameShard: unknown exchange {exchange!r}")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.exchange = exchange
+        self.bytes_sent = 0  # per-rank payload handed to the collectives since the last reset (accounting only)
+
+    # ---- partition ---------------------------------------------------------------------------------
+    def check(self, frames, hw):
+        if frames % self.world or hw % self.world:
+            raise RuntimeError(f"FrameShard: frames ({frames}) and pixels per frame ({hw}) must both be multiples of the "
+                               f"world size {self.world}")
+
+    def frame_range(self, frames):
+        n = frames // self.world
+        return self.rank * n, (self.rank + 1) * n
+
+    def pixel_range(self, hw):
+        n = hw // self.world
+        return self.rank * n, (self.rank + 1) * n
+
+    # ---- collectives (device tensors with nccl; staged through the host with gloo) -------------------
+    def _staged(self, t):
+        return self.backend == "gloo" and t.is_cuda
+
+    def all_gather(self, t):
+        """[...] -> [world, ...] in rank order"""
+        t = t.contiguous()
+        self.bytes_sent += t.numel() * t.element_size()
+        src = t.cpu() if self._staged(t) else t
+        out = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(out, src, group=self.group)
+        res = torch.stack(out)
+        return res.to(t.device) if self._staged(t) else res
+
+    def all_to_all(self, send):
+        """send [world, ...]: slice j goes to rank j -> recv [world, ...]: slice i came from rank i"""
+        send = send.contiguous()
+        assert send.shape[0] == self.world
+        if self.exchange == "allgather" or self.backend == "gloo":
+            return self.all_gather(send)[:, self.rank].contiguous()
+        self.bytes_sent += send.numel() * send.element_size() * (self.world - 1) // self.world
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    # ---- layout exchanges on canonical rows [B * frames * pixels, C] ----------------------------------
+    def to_pixel_shard(self, x, batch, frames_local, hw):
+        """rows (b, f_local, p) of this rank's frames -> rows (b, f, p_local) of ALL frames for this rank's pixel slab"""
+        n, c = self.world, x.shape[1]
+        hwl = hw // n
+        send = x.view(batch, frames_local, n, hwl, c).permute(2, 0, 1, 3, 4)  # [dst, B, Floc, hwl, C]
+        recv = self.all_to_all(send)                                            # [src = frame block, B, Floc, hwl, C]
+        out = recv if batch == 1 else recv.permute(1, 0, 2, 3, 4)
+        return out.reshape(batch * n * frames_local * hwl, c)
+
+    def to_frame_shard(self, y, batch, frames_local, hw):
+        """inverse of ``to_pixel_shard``"""
+        n, c = self.world, y.shape[1]
+        hwl = hw // n
+        send = y.view(batch, n, frames_local, hwl, c)
+        send = send if batch == 1 else send.permute(1, 0, 2, 3, 4)            # [dst = frame block, B, Floc, hwl, C]
+        recv = self.all_to_all(send.reshape(n, batch, frames_local, hwl, c))    # [src = pixel slab, B, Floc, hwl, C]
+        return recv.permute(1, 2, 0, 3, 4).reshape(batch * frames_local * hw, c)
+
+    def gather_frames(self, t, dim):
+        """all-gather along the frame dimension ``dim`` (model inputs / outputs, 4 channels: small)"""
+        parts = self.all_gather(t)
+        return torch.cat(list(parts.unbind(0)), dim=dim)

@@ -11,7 +11,7 @@ from . import _ffi
 from ._ffi import (A_CONV3X3, A_PLAIN, A_TEMPORAL3, ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc, GnDesc,
                    PnpDesc, TAttnDesc, check, lib)
 
-__all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "pnp_blend_tokens",
+__all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "groupnorm_moments", "groupnorm_apply_moments", "layernorm", "pnp_blend_tokens",
            "pnp_blend_nchw", "ddim_step", "latent_fusion", "timestep_embedding", "act", "add", "conv3x3_small",
            "adaptive_avgpool", "ncfhw_to_tokens", "tokens_to_ncfhw", "temporal_encoder4", "ACT_NONE", "ACT_GEGLU",
            "ACT_SILU", "ACT_GELU"]
@@ -179,22 +179,48 @@ def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
     return out
 
 
-def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2=None, out=None):
-    """GroupNorm over ``rows_per_sample`` rows x (C/groups) channels per sample, optional fused SiLU; [x | x2] concat."""
+def _gn_desc(x, gamma, beta, x2, out, nsample, rows_per_sample, groups, eps, silu):
     _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(x2, "x2")
     c1 = x.shape[1]
     c = c1 + (x2.shape[1] if x2 is not None else 0)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise RuntimeError("groupnorm: inputs must be contiguous")
-    if out is None:
-        out = torch.empty((nsample * rows_per_sample, c), dtype=torch.float16, device=x.device)
     wsb = lib.mvoc_groupnorm_workspace_bytes(nsample, rows_per_sample, c, groups)
     ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=x.device)
     d = GnDesc()
-    d.x, d.x2, d.gamma, d.beta, d.out = x.data_ptr(), _ptr(x2), gamma.data_ptr(), beta.data_ptr(), out.data_ptr()
+    d.x, d.x2, d.gamma, d.beta, d.out = x.data_ptr(), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.nsample, d.rows_per_sample, d.c, d.c1, d.groups, d.silu, d.eps = nsample, rows_per_sample, c, c1, groups, int(silu), eps
+    return d, ws
+
+
+def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2=None, out=None):
+    """GroupNorm over ``rows_per_sample`` rows x (C/groups) channels per sample, optional fused SiLU; [x | x2] concat."""
+    if out is None:
+        c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        out = torch.empty((nsample * rows_per_sample, c), dtype=torch.float16, device=x.device)
+    d, ws = _gn_desc(x, gamma, beta, x2, out, nsample, rows_per_sample, groups, eps, silu)
     check(lib.mvoc_groupnorm_f16(C.byref(d), _stream()), "groupnorm")
+    return out
+
+
+def groupnorm_moments(x, *, nsample, rows_per_sample, groups):
+    """This rank's {count, mean, M2} per (sample, group): fp32 [nsample, groups, 3] (first half of a sharded GroupNorm)."""
+    mom = torch.empty((nsample, groups, 3), dtype=torch.float32, device=x.device)
+    d, ws = _gn_desc(x, None, None, None, None, nsample, rows_per_sample, groups, 0.0, False)
+    check(lib.mvoc_groupnorm_moments_f16(C.byref(d), mom.data_ptr(), _stream()), "groupnorm_moments")
+    return mom
+
+
+def groupnorm_apply_moments(x, parts, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, out=None):
+    """Second half: ``parts`` fp32 [nparts, nsample, groups, 3] (all ranks' moments in rank order) -> normalised rows."""
+    _chk(parts, "parts", torch.float32)
+    if parts.dim() != 4 or tuple(parts.shape[1:]) != (nsample, groups, 3) or not parts.is_contiguous():
+        raise RuntimeError(f"groupnorm_apply_moments: parts must be contiguous [nparts, {nsample}, {groups}, 3]")
+    if out is None:
+        out = torch.empty((nsample * rows_per_sample, x.shape[1]), dtype=torch.float16, device=x.device)
+    d, ws = _gn_desc(x, gamma, beta, None, out, nsample, rows_per_sample, groups, eps, silu)
+    check(lib.mvoc_groupnorm_apply_moments_f16(C.byref(d), parts.data_ptr(), parts.shape[0], _stream()), "groupnorm_apply_moments")
     return out
 
 

@@ -190,6 +190,18 @@ class I2VGenXLPipeline:
                     image_embeddings=image_embeddings.to(self.device, H16).contiguous(),
                     image_latents=image_latents.to(self.device, H16).contiguous(), fps=fps)
 
+    def enable_frame_shard(self, shard):
+        """Frame-shard the UNet of this pipeline over the ranks of ``shard`` (``mvoc_amd.frame_shard.FrameShard``; BASELINE
+        configs[3]: one long clip on the 8 GPUs of a node).  Every rank runs the same loop on the same full latents (the
+        scheduler update is replicated, 4 channels); the UNet computes F/world frames per rank.  Loop iterations run
+        eagerly (torch.distributed issues the RCCL exchanges between the library's launches); rank 0 alone writes
+        ``ddim_latents_{t}.pt`` files."""
+        self.unet.set_frame_shard(shard)
+        self.use_graphs = False
+        self._graphs = {}
+        self.latent_cache.write_files = shard.rank == 0
+        return self
+
     # ---- one loop iteration each (static buffers so that they can be graph-captured) -------------------
     def _make_stock_step(self, key, latents, cond, guidance_scale):
         """iteration of invert / __call__: [cat x2] -> UNet -> CFG + (inverse-)DDIM update, in place on `state`"""

@@ -223,10 +223,15 @@ class TransformerTemporalModel(_TransformerBase):
         super().__init__(sd, prefix, cin, heads, groups, False)
 
     def forward(self, eng, x, geo):
+        return eng.temporal_section(x, geo, self._section)
+
+    def _section(self, eng, x, geo, full_hw):
+        """geo: (B, all F frames, H, W) of the rows in x -- the whole frames on one GPU, or this rank's pixel slab
+        (H = 1, W = slab length, ``full_hw`` = the real feature size) when the clip is frame-sharded"""
         B, F, H, W = geo
         hw = H * W
         blk = self.transformer_blocks[0]
-        h = ops.groupnorm(x, *self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, silu=False)
+        h = eng.groupnorm5d(x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, silu=False)
         h = self.proj_in(h)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
@@ -235,7 +240,7 @@ class TransformerTemporalModel(_TransformerBase):
             proc = attn.processor
             if attn is blk.attn1 and proc.injecting():
                 eng.check_pnp_batch(B, proc.mask)
-                masks = eng.device_masks(proc.mask)[0]  # soft float masks, channel 0
+                masks = eng.section_masks(proc.mask, 0, full_hw)  # soft float masks, channel 0
                 ld = qkv.stride(0)
                 ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
                                      f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
@@ -300,14 +305,17 @@ class TemporalConvLayer(Hookable):
                                 pack_tconv(g(f".conv{i}.{ci}.weight")), g(f".conv{i}.{ci}.bias")))
 
     def forward(self, eng, x, geo):
+        return eng.temporal_section(x, geo, self._section)
+
+    def _section(self, eng, x, geo, full_hw):
         B, F, H, W = geo
         hw = H * W
         h = x
         for i, (norm, w, b) in enumerate(self.stages):
-            h = ops.groupnorm(h, *norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-5, silu=True)
+            h = eng.groupnorm5d(h, norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-5, silu=True)
             h = ops.tconv3(h, w, b, nvid=B, frames=F, hw=hw, resid=x if i == 3 else None)
         if self.injecting():
-            eng.inject_features(h, self.mask, geo, h.shape[1])
+            eng.inject_features(h, self.mask, geo, h.shape[1], full_hw=full_hw)
         return h
 
 
@@ -365,7 +373,18 @@ class I2VGenXLUNet:
         self.dtype = H16
         self.num_upsamplers = len(self.config.block_out_channels) - 1
         self._mask_cache = (None, None)
+        self._section_mask_cache = {}
         self._loaded = False
+        self.shard = None  # mvoc_amd.frame_shard.FrameShard: frame-axis shard of one long clip (set_frame_shard)
+
+    def set_frame_shard(self, shard):
+        """Frame-shard every forward over the ranks of ``shard`` (``mvoc_amd.frame_shard``): each rank receives the FULL
+        inputs, computes its F/world frames (temporal sections pixel-sharded, see that module) and returns the FULL
+        output (one all-gather of the 4-channel prediction), so the loops around the UNet stay unchanged."""
+        self.shard = shard
+        self._mask_cache = (None, None)
+        self._section_mask_cache = {}
+        return self
 
     # ---- weights --------------------------------------------------------------------------------
     def expected_shapes(self):
@@ -485,24 +504,75 @@ class I2VGenXLUNet:
     def device_masks(self, mask_list):
         """list of (float [1,4,F,h,w], bool [1,4,F,h,w]) pairs (``register_time_all``'s ``mask``) ->
         (soft fp16 [nobj,F,h,w] from channel 0, hard {0,1} fp16 [nobj,F,h,w]); cached per mask list object."""
+        return self._all_frame_masks(mask_list)[2:]
+
+    def _all_frame_masks(self, mask_list):
+        """(soft, hard) over ALL frames, then the slices of this rank's frames (the same tensors without a frame shard)"""
         key = tuple((m[0].data_ptr(), m[1].data_ptr()) for m in mask_list)
         if self._mask_cache[0] != key:
             soft = torch.stack([m[0].reshape(-1, *m[0].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
             hard = torch.stack([m[1].reshape(-1, *m[1].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
-            self._mask_cache = (key, (soft, hard))
+            lsoft, lhard = soft, hard
+            if self.shard is not None:
+                f0, f1 = self.shard.frame_range(soft.shape[1])
+                lsoft, lhard = soft[:, f0:f1].contiguous(), hard[:, f0:f1].contiguous()
+            self._mask_cache = (key, (soft, hard, lsoft, lhard))
+            self._section_mask_cache = {}
         return self._mask_cache[1]
 
-    def inject_features(self, h, mask_list, geo, channels):
-        """feature injection (``pnp_utils.py:970-1004, 1059-1082, 1114-1146``): base = chunk 0, bool mask, no resize"""
+    def section_masks(self, mask_list, kind, full_hw):
+        """masks for a temporal section (kind 0 = soft, 1 = hard): all frames.  Frame-sharded, the section sees a slab of
+        pixels of every frame: the masks are nearest-resized to the feature size (``F.interpolate`` as at
+        ``pnp_utils.py:807``; the kernel's in-line resize is the same index rule), flattened and cut to the slab."""
+        full = self._all_frame_masks(mask_list)[kind]
+        if self.shard is None:
+            return full
+        key = (kind, tuple(full_hw))
+        if key not in self._section_mask_cache:
+            m = full
+            if tuple(m.shape[2:]) != tuple(full_hw):
+                m = torch.nn.functional.interpolate(m, size=tuple(full_hw), mode="nearest")  # [nobj, F, h, w]: F rides as channels
+            p0, p1 = self.shard.pixel_range(full_hw[0] * full_hw[1])
+            self._section_mask_cache[key] = m.reshape(m.shape[0], m.shape[1], 1, -1)[..., p0:p1].contiguous()
+        return self._section_mask_cache[key]
+
+    def inject_features(self, h, mask_list, geo, channels, full_hw=None):
+        """feature injection (``pnp_utils.py:970-1004, 1059-1082, 1114-1146``): base = chunk 0, bool mask, no resize.
+        ``full_hw`` is given by temporal sections (see ``section_masks``); elsewhere the rows are whole local frames."""
         B, F, H, W = geo
         self.check_pnp_batch(B, mask_list)
-        hard = self.device_masks(mask_list)[1]
-        if hard.shape[2] != H or hard.shape[3] != W:
-            raise RuntimeError(f"feature injection needs masks at the feature resolution {(H, W)}, got "
+        hard = self._all_frame_masks(mask_list)[1]
+        fh, fw = full_hw if full_hw is not None else (H, W)
+        if hard.shape[2] != fh or hard.shape[3] != fw:
+            raise RuntimeError(f"feature injection needs masks at the feature resolution {(fh, fw)}, got "
                                f"{tuple(hard.shape[2:])} (reference: pnp_utils.py:994-1000 has no resize)")
+        hard = self.section_masks(mask_list, 1, full_hw) if full_hw is not None else self.device_masks(mask_list)[1]
         ld = h.stride(0)
         ops.pnp_blend_tokens(h, hard, frames=F, height=H, width=W, channels=channels, chunk_stride=F * H * W * ld,
                              f_stride=H * W * ld, p_stride=ld, base_chunk0=True)
+
+    # ---- frame-axis shard plumbing --------------------------------------------------------------------
+    def temporal_section(self, x, geo, section):
+        """run ``section(eng, rows, geo, full_hw)`` on rows that hold ALL frames: as they are on one GPU, or exchanged
+        to the pixel-sharded layout and back when the clip is frame-sharded"""
+        sh = self.shard
+        B, F, H, W = geo
+        if sh is None:
+            return section(self, x, geo, (H, W))
+        hw = H * W
+        sh.check(F * sh.world, hw)
+        xp = sh.to_pixel_shard(x, B, F, hw)
+        yp = section(self, xp, (B, F * sh.world, 1, hw // sh.world), (H, W))
+        return sh.to_frame_shard(yp, B, F, hw)
+
+    def groupnorm5d(self, x, norm, *, nsample, rows_per_sample, groups, eps, silu):
+        """GroupNorm whose statistics span the whole video (``pnp_utils.py:185-188, 1048-1051``)"""
+        if self.shard is None:
+            return ops.groupnorm(x, *norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=silu)
+        mom = ops.groupnorm_moments(x, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups)
+        parts = self.shard.all_gather(mom)
+        return ops.groupnorm_apply_moments(x, parts, *norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups,
+                                           eps=eps, silu=silu)
 
     # ---- forward -----------------------------------------------------------------------------------
     def _embeddings(self, timestep, fps, B):
@@ -577,7 +647,15 @@ class I2VGenXLUNet:
         up_factor = 2 ** self.num_upsamplers
         forward_upsample_size = any(s % up_factor != 0 for s in (H, W))
         temb_act = self._embeddings(timestep, fps, B)
-        ctx = self._context(image_latents, image_embeddings, encoder_hidden_states, F, multi_frame_guidance)
+        sh = self.shard
+        f0, f1 = (0, F) if sh is None else sh.frame_range(F)
+        if sh is not None:
+            sh.check(F, hw)
+        if sh is not None and multi_frame_guidance:  # per-frame context: this rank's frames only
+            ie = image_embeddings if image_embeddings.dim() == 2 else image_embeddings[:, f0:f1]
+            ctx = self._context(image_latents[:, :, f0:f1], ie, encoder_hidden_states, f1 - f0, True)
+        else:  # one context per sample, built from frame 0 of the full clip
+            ctx = self._context(image_latents, image_embeddings, encoder_hidden_states, f1 - f0, multi_frame_guidance)
 
         # stem: image_latents_proj_in -> temporal encoder -> cat with sample -> conv_in -> transformer_in
         il = torch.empty((B * F * hw, 4), dtype=H16, device=self.device)
@@ -587,6 +665,11 @@ class I2VGenXLUNet:
         x8 = torch.empty((B * F * hw, 8), dtype=H16, device=self.device)
         ops.ncfhw_to_tokens(sample, x8, coff=0)
         ops.temporal_encoder4(il, self.enc4_params, x8, b=B, f=F, hw=hw, coff=4)
+        if sh is not None:
+            # the 4-channel stem above (three small convs + the frame-axis encoder) is computed for the whole clip on
+            # every rank -- 0.01 % of the step; from conv_in on, the rank holds only its own frames
+            x8 = x8.view(B, F, hw, 8)[:, f0:f1].reshape(-1, 8)
+            F = f1 - f0
         geo = (B, F, H, W)
         x, _, _ = ops.conv3x3(x8, self.conv_in.w, self.conv_in.b, nimg=B * F, h=H, wd=W, n_store=self.conv_in.cout)
         x = self.transformer_in.forward(self, x, geo)
@@ -640,5 +723,7 @@ class I2VGenXLUNet:
             out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)  # [B,C,F,h,w]
             nchw = out.permute(0, 2, 1, 3, 4).reshape(B * F, co.cout, H, W).contiguous()
             ops.pnp_blend_nchw(nchw, self.device_masks(co.mask)[1], frames=F, base_chunk0=True)
-            return nchw.reshape(B, F, co.cout, H, W).permute(0, 2, 1, 3, 4).contiguous()
-        return ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)
+            out = nchw.reshape(B, F, co.cout, H, W).permute(0, 2, 1, 3, 4).contiguous()
+        else:
+            out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)
+        return out if sh is None else sh.gather_frames(out, dim=2)

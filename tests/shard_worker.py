@@ -1,0 +1,168 @@
+"""Worker for the frame-shard tests (launched by torch.distributed.run, one process per rank, gloo backend).
+
+  exchange : CPU.  Every rank builds the same seeded "whole clip" tensor, takes its frame block, runs the FrameShard
+             exchanges and checks them against plain slicing of the whole tensor.
+  unet     : GPU.  Ranks share cuda:0 (the test boxes have one GPU; gloo stages the collectives through the host).  Every
+             rank runs the frame-sharded engine AND the unsharded engine on the same inputs and compares.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvoc_amd.frame_shard import FrameShard  # noqa: E402
+
+
+def exchange(out_dir):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    report = {"rank": rank, "cases": 0}
+    for mode in ("a2a", "allgather"):
+        sh = FrameShard(exchange=mode)
+        for (B, F, hw, C) in ((1, 4, 6, 8), (2, 4, 6, 8), (5, 2, 10, 16), (1, 8, 2, 8)):
+            g = torch.Generator().manual_seed(B * 1000 + F * 10 + hw)
+            whole = torch.randn(B, F, hw, C, generator=g).half()
+            f0, f1 = sh.frame_range(F)
+            p0, p1 = sh.pixel_range(hw)
+            mine = whole[:, f0:f1].reshape(-1, C).contiguous()
+            px = sh.to_pixel_shard(mine, B, f1 - f0, hw)
+            assert torch.equal(px, whole[:, :, p0:p1].reshape(-1, C)), (mode, B, F, hw, "to_pixel_shard")
+            back = sh.to_frame_shard(px, B, f1 - f0, hw)
+            assert torch.equal(back, mine), (mode, B, F, hw, "to_frame_shard")
+            full = sh.gather_frames(whole[:, f0:f1].permute(0, 3, 1, 2).contiguous(), dim=2)  # [B, C, F, hw]
+            assert torch.equal(full, whole.permute(0, 3, 1, 2)), (mode, "gather_frames")
+            mom = torch.full((B, 4, 3), float(rank))
+            parts = sh.all_gather(mom)
+            assert parts.shape == (world, B, 4, 3) and all(float(parts[r].mean()) == r for r in range(world))
+            report["cases"] += 1
+        try:
+            sh.check(7, 8)
+            raise AssertionError("check() accepted 7 frames")
+        except RuntimeError:
+            pass
+    json.dump(report, open(os.path.join(out_dir, f"exchange_r{rank}.json"), "w"))
+
+
+def unet(out_dir, which):
+    from mvoc_amd.unet import I2VGenXLUNet
+    from mvoc_amd.unet_spec import UNetConfig
+    from mvoc_amd import pnp_utils
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda:0"
+    # the 4-level toy of the oracle tests (full attribute tree the hooks address) or the production network
+    cfg = UNetConfig() if which == "full" else UNetConfig(
+        block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
+        attention_head_dim=64, transformer_in_heads=2, context_pool=8)
+    eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+    report = {"rank": rank}
+
+    def inputs(B, F, h, w, seed):
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s: torch.randn(*s, generator=g).half().to(dev)
+        return dict(sample=r(B, 4, F, h, w), fps=torch.full((B,), 8.0).to(dev), first=r(B, 4, F, h, w), lat=r(B, 4, F, h, w),
+                    emb=r(B, F, cfg.cross_attention_dim), ehs=r(B, 7, cfg.cross_attention_dim))
+
+    def run(x, mfg):
+        return eng.forward_ext(x["sample"], torch.tensor([500.0]).to(dev), x["fps"], x["first"], x["lat"], x["emb"], x["ehs"],
+                               multi_frame_guidance=mfg)[0].float()
+
+    def compare(name, B, F, h, w, mfg, hooks=None):
+        x = inputs(B, F, h, w, seed=B * 100 + F)
+        for mode in ("a2a", "allgather"):
+            eng.set_frame_shard(None)
+            if hooks:
+                hooks()
+            ref = run(x, mfg)
+            eng.set_frame_shard(FrameShard(exchange=mode))
+            if hooks:
+                hooks()
+            got = run(x, mfg)
+            eng.set_frame_shard(None)
+            assert got.shape == ref.shape
+            d = (got - ref).abs().max().item()
+            rel = ((got - ref).norm() / ref.norm()).item()
+            report[f"{name}_{mode}"] = {"max_abs": d, "rel_l2": rel, "ref_max": ref.abs().max().item()}
+            # every rank must hold the same full output (the loops around the UNet run replicated)
+            parts = FrameShard().all_gather(got)
+            assert all(torch.equal(parts[0], parts[r]) for r in range(world)), f"{name}: ranks disagree"
+
+    if which == "full":
+        compare("full_b1", 1, 16, 32, 32, False)
+    else:
+        F = 4 * world
+        compare("plain_b1", 1, F, 16, 16, False)
+        compare("multiframe_b2", 2, F, 16, 16, True)
+        # composition step: batch of 5 with every injection site live (soft temporal masks at a different resolution
+        # than some feature maps -> the nearest resize of the pixel-sharded masks is exercised)
+        g = torch.Generator().manual_seed(5)
+        hard = (torch.rand(2, 1, 1, F, 16, 16, generator=g) > 0.5).expand(2, 1, 4, F, 16, 16)
+        soft = (torch.randint(0, 256, (2, 1, 1, F, 16, 16), generator=g).float() / 255).half().expand(2, 1, 4, F, 16, 16)
+        masks = [(soft[j].contiguous().to(dev), hard[j].contiguous().to(dev)) for j in range(2)]
+
+        class Pipe:
+            unet = eng
+
+        def hooks():
+            sched = torch.tensor([500, 400])
+            pnp_utils.register_spatial_attention_pnp(Pipe, sched, True)
+            pnp_utils.register_temp_attention_pnp(Pipe, sched, True)
+            pnp_utils.register_temp_conv_injection(Pipe, sched)
+            pnp_utils.register_out_conv_injection(Pipe, sched)
+            pnp_utils.register_resnet_injection(Pipe, sched)
+            pnp_utils.register_time_all(Pipe, 500, masks)
+
+        compare("pnp_b5", 5, F, 16, 16, True, hooks)
+    json.dump(report, open(os.path.join(out_dir, f"unet_r{rank}.json"), "w"))
+
+
+def pipeline(out_dir):
+    """5-step DDIM inversion (cfg 7.5 -> UNet batch 2) through the pipeline: frame-sharded vs unsharded, files by rank 0 only"""
+    from mvoc_amd.unet import I2VGenXLUNet
+    from mvoc_amd.unet_spec import UNetConfig
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda:0"
+    cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
+                     attention_head_dim=64, transformer_in_heads=2, context_pool=8)
+    f, h, w = 2 * world, 16, 16
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g).half().to(dev)
+    x0, pe, ne, ie, il = r(1, 4, f, h, w), r(1, 7, 64), r(1, 7, 64), r(1, 1, 64), r(1, 4, f, h, w)
+    seqs = []
+    for sharded in (False, True):
+        eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+        pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=not sharded)
+        if sharded:
+            pipe.enable_frame_shard(FrameShard())
+        d = os.path.join(out_dir, f"lat_{'shard' if sharded else 'single'}_r{rank}" if not sharded else "lat_shard")
+        inv = pipe.invert(height=h * 8, width=w * 8, num_frames=f, num_inference_steps=5, guidance_scale=7.5, target_fps=8,
+                          latents=x0, prompt_embeds=pe, negative_prompt_embeds=ne, image_embeddings=ie, image_latents=il,
+                          return_dict=False, output_dir=d)
+        seqs.append(inv.float())
+    dist.barrier()
+    diff = (seqs[0] - seqs[1]).abs().max().item()
+    files = sorted(os.listdir(os.path.join(out_dir, "lat_shard")))
+    same = all(torch.equal(torch.load(os.path.join(out_dir, "lat_shard", f"ddim_latents_{t}.pt")), seqs[1][0, 4 - i][None].half().cpu())
+               for i, t in enumerate((1, 201, 401, 601, 801)))
+    json.dump({"rank": rank, "max_abs": diff, "files": files, "files_match": same},
+              open(os.path.join(out_dir, f"pipeline_r{rank}.json"), "w"))
+
+
+if __name__ == "__main__":
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    try:
+        if mode == "exchange":
+            exchange(out_dir)
+        elif mode == "pipeline":
+            pipeline(out_dir)
+        else:
+            unet(out_dir, sys.argv[3] if len(sys.argv) > 3 else "tiny")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,96 @@
+"""GPU: the frame-sharded UNet forward (SURVEY 8e / BASELINE configs[3]) against the unsharded forward of the same
+engine on the same inputs.  Two ranks share the box's single GPU; the gloo backend stages the collectives through the
+host, which exercises exactly the code path RCCL takes on a multi-GPU node except for the transport.
+
+What may differ: the order in which GroupNorm moments are merged (per rank, then across ranks) and the GEMM tile chosen
+for the smaller per-rank row counts -- fp32 accumulation-order noise under fp16 outputs.  Tolerance: rel-L2 <= 5e-3,
+max-abs <= 3e-2 * max|ref| (the bound the engine-vs-oracle tests use); in practice the differences are ~1e-3."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(nproc, port, *args, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "tests", "shard_worker.py"), *args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+
+
+def check(rep):
+    seen = 0
+    for name, v in rep.items():
+        if not isinstance(v, dict):
+            continue
+        seen += 1
+        assert v["rel_l2"] <= 5e-3 and v["max_abs"] <= 3e-2 * v["ref_max"], (name, v)
+    return seen
+
+
+def test_groupnorm_moments_pair_is_bit_exact():
+    """moments + apply with one part == the fused GroupNorm, bit for bit; with the rows split in two parts the merged
+    statistics agree to fp32 rounding"""
+    import torch
+    from mvoc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, R, C, G = 2, 4 * 36, 64, 8
+    x = (torch.randn(B * R, C, generator=g) * 2 + 0.5).half().cuda()
+    gamma, beta = torch.randn(C, generator=g).half().cuda(), torch.randn(C, generator=g).half().cuda()
+    ref = ops.groupnorm(x, gamma, beta, nsample=B, rows_per_sample=R, groups=G, eps=1e-5, silu=True)
+    mom = ops.groupnorm_moments(x, nsample=B, rows_per_sample=R, groups=G)
+    got = ops.groupnorm_apply_moments(x, mom[None].contiguous(), gamma, beta, nsample=B, rows_per_sample=R, groups=G, eps=1e-5,
+                                      silu=True)
+    assert torch.equal(ref, got)
+    # two "ranks": each holds half the rows of every sample
+    xs = x.view(B, 2, R // 2, C)
+    halves = [xs[:, i].reshape(-1, C).contiguous() for i in range(2)]
+    parts = torch.stack([ops.groupnorm_moments(h, nsample=B, rows_per_sample=R // 2, groups=G) for h in halves])
+    outs = [ops.groupnorm_apply_moments(h, parts, gamma, beta, nsample=B, rows_per_sample=R // 2, groups=G, eps=1e-5, silu=True)
+            for h in halves]
+    got2 = torch.stack([o.view(B, R // 2, C) for o in outs], dim=1).reshape(B * R, C)
+    assert (got2.float() - ref.float()).abs().max().item() <= 2e-3
+    # statistics against torch in fp64
+    xv = x.double().view(B, R, G, C // G)
+    assert torch.allclose(mom[..., 1].double().cpu(), xv.mean(dim=(1, 3)).cpu(), atol=1e-5)
+    assert torch.allclose((mom[..., 2] / mom[..., 0]).double().cpu(), xv.var(dim=(1, 3), unbiased=False).cpu(), rtol=1e-4)
+
+
+def test_sharded_forward_matches_unsharded_world2(tmp_path):
+    r = launch(2, 29551, "unet", str(tmp_path), "tiny")
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    for rank in range(2):
+        rep = json.load(open(tmp_path / f"unet_r{rank}.json"))
+        assert check(rep) == 6, rep  # plain / multi-frame / PnP batch of 5, two exchange forms each
+
+
+def test_sharded_forward_world1_is_identity(tmp_path):
+    """world size 1: the exchanges are no-ops and the moments pair is bit-exact -> the outputs must be identical"""
+    r = launch(1, 29552, "unet", str(tmp_path), "tiny")
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.load(open(tmp_path / "unet_r0.json"))
+    for name, v in rep.items():
+        if isinstance(v, dict):
+            assert v["max_abs"] == 0.0, (name, v)
+
+
+def test_sharded_forward_full_network_world2(tmp_path):
+    r = launch(2, 29553, "unet", str(tmp_path), "full")
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.load(open(tmp_path / "unet_r0.json"))
+    assert check(rep) == 2, rep
+
+
+def test_sharded_inversion_loop_world2(tmp_path):
+    """pipe.invert on a frame-sharded UNet: same latents as the single-GPU loop (5 steps, cfg 7.5: <= 3e-2 like the
+    loop-vs-oracle tests; observed 2e-2: cfg 7.5 amplifies the per-forward 2e-3), one set of ddim_latents files written by rank 0"""
+    r = launch(2, 29554, "pipeline", str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    for rank in range(2):
+        rep = json.load(open(tmp_path / f"pipeline_r{rank}.json"))
+        assert rep["max_abs"] <= 3e-2, rep
+        assert rep["files"] == sorted(f"ddim_latents_{t}.pt" for t in (1, 201, 401, 601, 801)) and rep["files_match"], rep
