@@ -15,7 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified register file).  In AGPR form hipcc time-shares
 # 32 AGPRs between the S^T and O^T accumulators and emits ~220 v_accvgpr_read/write per K/V tile; VGPR form has none
 # and needs 162 instead of 196 registers (3 waves per SIMD instead of 2).
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# gemm: neutral for the 32-row-per-wave tiles (same speed, no accvgpr traffic), required by the 64-row-per-wave tiles
+# (160 / 128 accumulator registers + operands fit 256 unified registers only in this form -> 2 waves per SIMD).
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   const int nk = p.k_per_split / BKK;
   const int swz = MVOC_SWZ(r);  // tile bases are multiples of 32 rows: the swizzle depends on r only
   float ln_s1 = 0.f, ln_s2 = 0.f;
-  static_assert(WN * WM * 64 == 2 * BM, "LayerNorm folding assumes two threads per staged activation row");
+  static_assert(BKK != 64 || TM != 1 || WN * WM * 64 == 2 * BM, "in-kernel LayerNorm statistics assume two threads per staged activation row");
   issue(0);
   if (NST == 3 && nk > 1) issue(1);
   int cur = 0;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
-    if (BKK == 64 && p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
+    if (BKK == 64 && WN * WM * 64 == 2 * BM && p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
       const int srow = tid >> 1;
       const char* rp = smem + cur * STAGE + BN * ROW + srow * ROW;
       const int rsw = (srow >> 1) & 7;
@@ -710,13 +710,39 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                  -2, "gemm: LayerNorm folding needs the plain single-source direct-to-LDS path (k %% 64 == 0), no split-K");
   }
   int tile = d->tile;
-  if (tile == 0 && glds_ok) {  // measured per shape on MI355X (tools/gemm_bench.py)
-    if (d->act == MVOC_ACT_GEGLU) tile = d->m >= 8192 ? 15 : 11;
-    else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) tile = 13;  // few rows and no split-K: small tiles
-    else if (d->m <= 8192 && d->n % 128 == 0) tile = 11;
-    else if (d->n % 160 == 0) tile = 12;
-    else if (d->n % 128 == 0) tile = 11;
-    else tile = 13;
+  int model_sk = 0;
+  if (tile == 0 && glds_ok) {
+    if (d->act == MVOC_ACT_GEGLU) {
+      // measured (tools/gemm_bench.py): 128x256 tiles win from 16 K rows up (the K-step-32 one needs precomputed LN statistics)
+      const bool stats_in_kernel = d->ln_rowsum && !d->ln_stats;
+      tile = d->m >= 16384 ? (stats_in_kernel ? 15 : 65) : 11;
+    } else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) {
+      tile = 13;  // few rows and no split-K: many small blocks (latency-bound regime, outside the model below)
+    } else {
+      // Pick the tile by a wave-quantisation cost model calibrated on MI355X (tools/gemm_bench.py, B = 1 and B = 5 shape
+      // sets): a launch runs in "waves" of `slots` resident blocks (2 per CU); a
+      // partly filled last wave costs 0.3 + 0.7 * fill of a full one; a block costs bm * bn * k_slice / eff.
+      static const struct { int tile, bn, bm, slots; float eff; } cand[] = {
+          {12, 160, 128, 512, 1.00f}, {11, 128, 128, 512, 0.94f}, {64, 160, 256, 512, 1.05f}};
+      const bool can_split = d->workspace && d->split_k == 0 && !d->ln_rowsum;
+      double best = 0;
+      for (const auto& c : cand) {
+        if (d->n % c.bn) continue;
+        if (c.tile == 64 && (d->m < 65536 || d->k < 4096 || (d->ln_rowsum && !d->ln_stats))) continue;
+        const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn);
+        int sk = 1;
+        if (can_split && blocks < 384)
+          while (sk < 8 && blocks * sk < 512 && d->k % (64 * sk * 2) == 0 && d->k / (sk * 2) >= 512) sk *= 2;
+        if (sk > 1 && (size_t)sk * d->m * d->n * 4 > d->workspace_bytes) sk = 1;
+        const double w = (double)(blocks * sk) / c.slots;
+        const double full = (double)(long)w, frac = w - full;
+        const double waves = full + (frac > 0 ? 0.3 + 0.7 * frac : 0.0);
+        double cost = waves * 2.0 * c.bm * c.bn * (double)(d->k / sk) / (1.66e6 * c.eff);      // us
+        if (sk > 1) cost += 5.0 + 2.0 * sk * (double)d->m * d->n * 4.0 / 3.0e6;                // fp32 slabs + reduce pass
+        if (tile == 0 || cost < best) { best = cost; tile = c.tile; model_sk = sk; }
+      }
+      if (tile == 0) tile = 13;  // n is a multiple of neither 160 nor 128
+    }
   }
   if (tile == 0) {
     if (d->act == MVOC_ACT_GEGLU) tile = 1;
@@ -726,11 +752,13 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
-    const int bm = tile == 14 || tile % 10 == 5 ? 256 : 128;
-    const int bn = (tile % 10 == 2 || tile == 14) ? 160 : (tile % 10 == 3 ? 64 : 128);  // x1: 128, x2: 160, x3: 64
+    const int bm = tile == 14 || tile == 64 || tile % 10 == 5 ? 256 : 128;
+    const int bn = (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);  // x1: 128, x2: 160, x3: 64
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
-    if (d->split_k == 0 && blocks < 384) {
+    if (model_sk > 0) {
+      sk = model_sk;
+    } else if (d->split_k == 0 && blocks < 384) {
       while (sk < 8 && blocks * sk < 512 && d->k % (64 * sk * 2) == 0 && d->k / (sk * 2) >= 512) sk *= 2;
     }
     if (sk > 1 && d->k % (64 * sk) == 0 && (size_t)sk * d->m * d->n * 4 <= d->workspace_bytes) {
@@ -785,6 +813,14 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 63:
       MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 63 needs k, cin, c1 %% 64 == 0 and row statistics");
       return launch_glds<1, 4, 2, 1, 2, 0, 32>(a, s);
+    // 64-row-per-wave register tiles (fewer LDS reads per MFMA), K step 32 so that two blocks still fit a CU
+    case 64:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
+                   "gemm: tile 64 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
+      return launch_glds<1, 4, 5, 2, 2, 0, 32>(a, s);  // 160 x 256
+    case 65:
+      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 65 needs k, cin, c1 %% 64 == 0 and row statistics");
+      return launch_glds<1, 4, 4, 2, 2, 0, 32>(a, s);  // 128 x 256
     case 52:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 52 needs k, cin, c1 %% 64 == 0 and no GEGLU");
       return launch_glds<1, 4, 5, 1, 2, 2>(a, s);  // 160 x 128 with s_setprio around the MFMA clusters
