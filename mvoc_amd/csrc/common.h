@@ -38,7 +38,8 @@ struct MvocProfScope {
 };
 
 // ---- device helpers ----------------------------------------------------------------------------
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp + v_rcp (1 ulp) instead of an IEEE division (~10 VALU ops): GroupNorm+SiLU apply is VALU-co-limited otherwise
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // erf-GELU for GEMM epilogues: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below the fp16 output ulp)
 // with one v_exp + one v_rcp instead of libm erff's ~40-instruction polynomial ladder

@@ -48,6 +48,7 @@ struct GemmArgs {
   float ln_eps;
   int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
   float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
+  int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 
 struct RowInfo {   // per staged activation row (fixed for the whole K loop)
@@ -155,6 +156,126 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
         }
       }
     }
+  }
+}
+
+// Epilogue of the direct-to-LDS kernels: same arithmetic (and the same fp16 rounding points) as gemm_epilogue, but the
+// output tile goes through LDS so that global stores and residual loads are 16 bytes per lane with consecutive lanes on
+// consecutive chunks of a row.  In the accumulator layout a lane owns 4 channels (8 B) of one pixel and the 32 lanes of
+// a store instruction hit 32 different rows: 8-byte row-strided requests, which bounded the K = 320 GEMMs
+// (M x 320 x 320 moved 2 TB/s).  Everything up to the activation is applied in the accumulator layout (bias / LN-fold /
+// row-add vectors are per channel there: broadcast loads), the fp16-rounded result is parked in a wave-private LDS
+// tile [32 pixels][TO*32 channels] (pitch + 16 B: conflict-free 8-byte writes), read back as 16-byte row chunks, the
+// residual added, stored.  `lds` = this wave's region (32 * (TO*64+16) bytes), free once every wave left the K loop.
+template <int WN, int WM, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&acc)[TN][TM], int n0, int m0, int wn, int wm,
+                                                  int r, int h, int lane, char* lds, const float* lnstat) {
+  const bool geglu = p.act == MVOC_ACT_GEGLU;
+  const bool use_bias = p.bias && !lnstat;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int mrow = (wm * TM + j) * 32;
+    const int m_own = m0 + mrow + r;
+    const int m_safe = m_own < p.M ? m_own : p.M - 1;
+    const half_t* ra = p.rowadd ? p.rowadd + (size_t)(m_safe / p.rowadd_div) * p.ld_rowadd : nullptr;
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (lnstat && m_own < p.M) {  // the statistics buffer ends at row M
+      ln_mu = lnstat[2 * (mrow + r)];
+      ln_rs = lnstat[2 * (mrow + r) + 1];
+    }
+    int TO = TN;
+    if (geglu) {
+      if constexpr (TN % 2 == 0) {
+        TO = TN / 2;
+        const int pitch = TO * 64 + 16;
+#pragma unroll
+        for (int i = 0; i < TN; i += 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nh = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;  // packed row of the value half
+            half4_t o = {0, 0, 0, 0};
+            if (nh < p.N) {
+              half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+              if (use_bias) {
+                bh = *reinterpret_cast<const half4_t*>(p.bias + nh);
+                bg = *reinterpret_cast<const half4_t*>(p.bias + nh + 32);
+              }
+              f32x4 sh = {0.f, 0.f, 0.f, 0.f}, sg = sh, ch = sh, cg = sh;
+              if (lnstat) {
+                sh = *reinterpret_cast<const f32x4*>(p.ln_s + nh);
+                sg = *reinterpret_cast<const f32x4*>(p.ln_s + nh + 32);
+                ch = *reinterpret_cast<const f32x4*>(p.ln_c + nh);
+                cg = *reinterpret_cast<const f32x4*>(p.ln_c + nh + 32);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float hv = r16(lnstat ? ln_rs * (acc[i][j][q * 4 + e] - ln_mu * sh[e]) + ch[e] : acc[i][j][q * 4 + e] + (float)bh[e]);
+                const float gv = r16(lnstat ? ln_rs * (acc[i + 1][j][q * 4 + e] - ln_mu * sg[e]) + cg[e]
+                                            : acc[i + 1][j][q * 4 + e] + (float)bg[e]);
+                o[e] = (half_t)(hv * r16(gelu_fast_f(gv)));
+              }
+            }
+            *reinterpret_cast<half4_t*>(lds + r * pitch + ((i / 2) * 32 + 8 * q + 4 * h) * 2) = o;
+          }
+        }
+      }
+    } else {
+      const int pitch = TN * 64 + 16;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + (wn * TN + i) * 32 + 8 * q + 4 * h;
+          half4_t o = {0, 0, 0, 0};
+          if (n < p.n_store) {
+            half4_t b4 = {0, 0, 0, 0};
+            if (use_bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
+            float v[4];
+            if (lnstat) {
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+              const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.ln_c + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = r16(ln_rs * (acc[i][j][q * 4 + e] - ln_mu * s4[e]) + c4[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = r16(acc[i][j][q * 4 + e] + (float)b4[e]);
+            }
+            if (ra) {
+              const half4_t t4 = *reinterpret_cast<const half4_t*>(ra + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
+            }
+            if (p.act == MVOC_ACT_SILU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+            } else if (p.act == MVOC_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+          }
+          *reinterpret_cast<half4_t*>(lds + r * pitch + (i * 32 + 8 * q + 4 * h) * 2) = o;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (DS ops of a wave execute in order)
+    // ---- read back as rows: chunk = 8 consecutive channels (16 B) of one pixel ---------------------------
+    const int nchunk = 4 * TO, pitch = TO * 64 + 16;
+    const int nbase = geglu ? (n0 + wn * TN * 32) / 2 : n0 + wn * TN * 32;
+    for (int idx = lane; idx < 32 * nchunk; idx += 64) {
+      const int px = idx / nchunk, c = idx - px * nchunk;
+      const int m = m0 + mrow + px, n = nbase + c * 8;
+      if (m >= p.M || n >= p.n_store) continue;
+      half8_t v = *reinterpret_cast<const half8_t*>(lds + px * pitch + c * 16);
+      if (p.resid) {
+        const half8_t r8 = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
+      }
+      *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next j overwrites the tile
   }
 }
 
@@ -576,6 +697,15 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     return;
   }
+  constexpr int EPI_BYTES = 32 * (TN * 64 + 16);  // per-wave LDS tile of the transposing epilogue
+  if constexpr (NW * EPI_BYTES <= NST * STAGE) {
+    if (p.epi_lds && !(p.ln_s && !p.ln_stats)) {
+      __syncthreads();  // every wave is out of the K loop: the staging buffers are free
+      gemm_epilogue_lds<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES,
+                                        p.ln_s ? p.ln_stats + 2 * (size_t)m0 : nullptr);
+      return;
+    }
+  }
   if (p.ln_s && p.ln_stats) {
     gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, p.ln_stats + 2 * (size_t)m0);
     return;
@@ -685,6 +815,11 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
   a.ln_s = (const float*)d->ln_rowsum; a.ln_c = (const float*)d->ln_bias; a.ln_eps = d->ln_eps;
   a.ln_stats = (const float*)d->ln_stats;
+  {
+    const int ns = d->act == MVOC_ACT_GEGLU ? (int)d->n / 2 : (d->n_store > 0 ? d->n_store : (int)d->n);
+    a.epi_lds = d->ldo % 8 == 0 && ns % 8 == 0 && ((uintptr_t)d->out & 15) == 0 &&
+                (d->resid == nullptr || (d->ldr % 8 == 0 && ((uintptr_t)d->resid & 15) == 0));
+  }
   if (d->a_mode == MVOC_A_CONV3X3) {
     MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
     MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");

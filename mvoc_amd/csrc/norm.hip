@@ -45,7 +45,23 @@ __global__ __launch_bounds__(256) void gn_partial(const GnArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (on) {
-      for (int rr = r0 + ry; rr < r1; rr += p.RY) {
+      // four 16-byte loads in flight per thread (one was not enough to cover HBM latency: 1.7 TB/s); the accumulation
+      // order per thread is unchanged, so the statistics are bit-identical to the rolled loop
+      int rr = r0 + ry;
+      for (; rr + 3 * p.RY < r1; rr += 4 * p.RY) {
+        half8_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.RY, cc * 8));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[u][e];
+            s[e] += f;
+            q[e] += f * f;
+          }
+      }
+      for (; rr < r1; rr += p.RY) {
         const half8_t v = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr, cc * 8));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -175,7 +191,24 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
       sc[e] = rstd * (float)gm[e];
       sh[e] = (float)bt[e] - mean * sc[e];
     }
-    for (int rr = r0 + ry; rr < r1; rr += p.RY) {
+    int rr = r0 + ry;
+    for (; rr + 3 * p.RY < r1; rr += 4 * p.RY) {  // four loads in flight per thread
+      half8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.RY, cc * 8));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = r16((float)v[u][e] * sc[e] + sh[e]);
+          if (p.silu) y = silu_f(y);
+          o[e] = (half_t)y;
+        }
+        *reinterpret_cast<half8_t*>(p.out + (rowbase + rr + u * p.RY) * p.c + cc * 8) = o;
+      }
+    }
+    for (; rr < r1; rr += p.RY) {
       const half8_t v = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr, cc * 8));
       half8_t o;
 #pragma unroll
