@@ -452,7 +452,10 @@ int launch(const GemmArgs& a0, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int WN, int WM, int TN, int TM, int NST, int PF = 0, int BKK = 64>
+// PLAIN = 1: single-source plain linear (no taps, no second source, no upsampling) -- the per-K-step address work is one
+// pointer bump per LDS-DMA instead of the general gather bookkeeping (the K <= 1280 projections were VALU-issue bound:
+// ~22 non-MFMA instructions per MFMA in the general loop)
+template <int WN, int WM, int TN, int TM, int NST, int PF = 0, int BKK = 64, int PLAIN = 0>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
   static_assert(BKK == 64 || BKK == 32, "K step of 64 (128-byte staged rows) or 32 (64-byte rows)");
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
@@ -542,6 +545,9 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     cch[i] = (pos ^ MVOC_SWZ(row)) * 8;
   }
+  const half_t* aptr[PA];  // PLAIN: the lane's source pointer per staged row, bumped by one K step per issue
+#pragma unroll
+  for (int i = 0; i < PA; ++i) aptr[i] = (vmask[i] & 1u) ? p.a + (size_t)rowoff[i] * p.lda + cch[i] + kbeg : zsrc;
   int tap = kbeg / p.cin, ch0 = kbeg - tap * p.cin;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
   // weight pointers advance by one K step per issue; rows beyond N read the zero constant with stride 0
   const half_t* wptr[PW];
@@ -556,6 +562,16 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[i],
                                          (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
       wptr[i] += wok[i] ? BKK : 0;
+    }
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
+                                         (__attribute__((address_space(3))) void*)(base + BN * ROW + (wave + i * NW) * 1024),
+                                         16, 0, 0);
+        aptr[i] += (vmask[i] & 1u) ? BKK : 0;
+      }
+      return;
     }
     // wave-uniform part of the gather (scalar registers)
     const bool second = ch0 >= p.c1;
@@ -766,7 +782,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0, int BKK = 64>
+template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0, int BKK = 64, int PLAIN = 0>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -777,7 +793,7 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK, PLAIN>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
   if (a.split_k > 1) {
     const long nthr = (long)a.M * (a.N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -906,6 +922,17 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       a.split_k = sk;
       a.k_per_split = (int)(d->k / sk);
       a.ws = (float*)d->workspace;
+    }
+  }
+  if (glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && !d->upsample && !(d->ln_rowsum && !d->ln_stats)) {
+    switch (tile) {  // the tiles the selection above produces, in their single-source plain-linear form
+      case 11: return launch_glds<2, 2, 2, 2, 2, 0, 64, 1>(a, s);
+      case 12: if (d->act != MVOC_ACT_GEGLU) return launch_glds<1, 4, 5, 1, 2, 0, 64, 1>(a, s); break;
+      case 13: return launch_glds<1, 4, 2, 1, 2, 0, 64, 1>(a, s);
+      case 61: return launch_glds<2, 2, 2, 2, 2, 0, 32, 1>(a, s);
+      case 62: if (d->act != MVOC_ACT_GEGLU) return launch_glds<1, 4, 5, 1, 2, 0, 32, 1>(a, s); break;
+      case 65: return launch_glds<1, 4, 4, 2, 2, 0, 32, 1>(a, s);
+      default: break;
     }
   }
   switch (tile) {

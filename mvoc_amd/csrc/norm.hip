@@ -109,10 +109,15 @@ __device__ __forceinline__ void gn_merge(GnMoments& a, float nb, float mb, float
 
 __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
   __shared__ float ln[1024], lmean[1024], lm2[1024];
+  // grid (nsample, gridDim.y): block y merges groups [y*GL, (y+1)*GL).  With few samples (the 5-D norms of a B = 1 step:
+  // ONE sample, up to 1024 slabs) a single block was a serial chain of four dependent load rounds (11 us); four blocks
+  // of 8 groups give every group 128 lanes -> one load round + a 7-level tree.
+  const int GL = p.G / gridDim.y;
   const int tid = threadIdx.x, smp = blockIdx.x;
   int lanes = 1;
-  while (lanes * 2 * p.G <= 1024) lanes *= 2;  // power of two
-  const int g = tid % p.G, lane = tid / p.G;
+  while (lanes * 2 * GL <= 1024) lanes *= 2;  // power of two
+  const int gl = tid % GL, lane = tid / GL;
+  const int g = blockIdx.y * GL + gl;
   GnMoments acc = {0.f, 0.f, 0.f};
   if (lane < lanes) {
     const float* base = p.ws + ((long)smp * p.nchunk * p.G + g) * 3;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
   __syncthreads();
   for (int half = lanes / 2; half >= 1; half /= 2) {
     if (lane < half) {
-      const int o = (lane + half) * p.G + g;
+      const int o = (lane + half) * GL + gl;
       gn_merge(acc, ln[o], lmean[o], lm2[o]);
       ln[tid] = acc.n; lmean[tid] = acc.mean; lm2[tid] = acc.m2;
     }
@@ -221,6 +226,9 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
     }
   }
 }
+
+// group-blocks per sample for gn_final: split the groups over 4 blocks when there are few samples and many slabs
+int gn_final_blocks(const GnArgs& a) { return (a.nsample < 16 && a.nchunk > 64 && a.G % 4 == 0 && a.G >= 8) ? 4 : 1; }
 
 void gn_geometry(GnArgs& a) {
   const int cchunks = a.c / 8;
@@ -371,7 +379,7 @@ extern "C" int mvoc_groupnorm_moments_f16(const mvoc_gn_desc* d, void* moments, 
   hipStream_t s = (hipStream_t)stream;
   MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
   hipLaunchKernelGGL(gn_partial, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
   return mvoc_check_launch("groupnorm_moments");
 }
 
@@ -396,7 +404,7 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
   MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
   dim3 grid(a.nchunk, a.nsample);
   hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(gn_final, dim3(a.nsample), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");
 }
