@@ -548,6 +548,10 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   const half_t* aptr[PA];  // PLAIN: the lane's source pointer per staged row, bumped by one K step per issue
 #pragma unroll
   for (int i = 0; i < PA; ++i) aptr[i] = (vmask[i] & 1u) ? p.a + (size_t)rowoff[i] * p.lda + cch[i] + kbeg : zsrc;
+  int astep[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) astep[i] = 0;
+  bool regather = true;
   int tap = kbeg / p.cin, ch0 = kbeg - tap * p.cin;  // wave-uniform position of the current K step: k0 = tap*cin + ch0
   // weight pointers advance by one K step per issue; rows beyond N read the zero constant with stride 0
   const half_t* wptr[PW];
@@ -573,31 +577,41 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
       }
       return;
     }
-    // wave-uniform part of the gather (scalar registers)
-    const bool second = ch0 >= p.c1;
-    const half_t* sbase = second ? p.a2 : p.a;
-    const int ld = second ? p.lda2 : p.lda;
-    const int cbase = second ? ch0 - p.c1 : ch0;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    int tap_rows = 0;
-    if (p.a_mode == MVOC_A_CONV3X3) tap_rows = ky * p.wsrc + kx;
-    else if (p.a_mode == MVOC_A_TEMPORAL3) tap_rows = (tap - 1) * p.hw;
+    // General gather.  The lane's source pointer only changes non-trivially when the K position crosses a tap or moves to
+    // the second source (every cin/BKK or c1/BKK steps): those wave-uniform events rebuild the pointers; every other step
+    // is a pointer bump, as in the plain path.
+    if (regather) {
+      const bool second = ch0 >= p.c1;
+      const half_t* sbase = second ? p.a2 : p.a;
+      const int ld = second ? p.lda2 : p.lda;
+      const int cbase = second ? ch0 - p.c1 : ch0;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      int tap_rows = 0;
+      if (p.a_mode == MVOC_A_CONV3X3) tap_rows = ky * p.wsrc + kx;
+      else if (p.a_mode == MVOC_A_TEMPORAL3) tap_rows = (tap - 1) * p.hw;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const bool ok = (vmask[i] >> tap) & 1u;
+        long srow = rowoff[i] + tap_rows;
+        if (p.upsample) {  // nearest-upsampled source: the row is not affine in the tap
+          const int iy = min((int)floorf((ry0[i] + ky) * p.ups_sh), p.hsrc - 1);
+          const int ix = min((int)floorf((rx0[i] + kx) * p.ups_sw), p.wsrc - 1);
+          srow = ((long)rimg[i] * p.hsrc + iy) * p.wsrc + ix;
+        }
+        aptr[i] = ok ? sbase + srow * ld + (cbase + cch[i]) : zsrc;
+        astep[i] = ok ? BKK : 0;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const bool ok = (vmask[i] >> tap) & 1u;
-      long srow = rowoff[i] + tap_rows;
-      if (p.upsample) {  // nearest-upsampled source: the row is not affine in the tap
-        const int iy = min((int)floorf((ry0[i] + ky) * p.ups_sh), p.hsrc - 1);
-        const int ix = min((int)floorf((rx0[i] + kx) * p.ups_sw), p.wsrc - 1);
-        srow = ((long)rimg[i] * p.hsrc + iy) * p.wsrc + ix;
-      }
-      const half_t* src = ok ? sbase + srow * ld + (cbase + cch[i]) : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
                                        (__attribute__((address_space(3))) void*)(base + BN * ROW + (wave + i * NW) * 1024),
                                        16, 0, 0);
+      aptr[i] += astep[i];
     }
     ch0 += BKK;
-    if (ch0 >= p.cin) { ch0 = 0; ++tap; }
+    regather = ch0 == p.c1;  // the next step starts reading the second source (never true for single-source calls: c1 == cin)
+    if (ch0 >= p.cin) { ch0 = 0; ++tap; regather = true; }
   };
 
   f32x16 acc[TN][TM];
