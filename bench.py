@@ -235,7 +235,7 @@ def cpu_baseline(frames, latent):
     # op sizes: 32 threads is what is used and what `cores` reports
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    sample_hw = 32  # ~5 TFLOP per forward: two timed forwards are 10-20 s of CPU work on 32 threads
+    sample_hw = 32  # ~5 TFLOP per forward: three timed forwards are ~15 s of CPU work on 32 threads
     cfg = UNetConfig()
     with torch.device("meta"):
         model = U.I2VGenXLUNet(U.UNetConfig())
@@ -252,14 +252,14 @@ def cpu_baseline(frames, latent):
         eh = torch.randn(b, 77, 1024)
         fps = torch.tensor([8])
         t0 = time.time()
-        for _ in range(2):
+        for _ in range(3):
             model(x, 981, fps, il, ie, eh)
-        dt = (time.time() - t0) / 2
+        dt = (time.time() - t0) / 3
     fl_sample = unet_flops(cfg, 1, frames, sample_hw, sample_hw)["total"]
     fl_step = (3 * unet_flops(cfg, 1, frames, latent, latent)["total"] + unet_flops(cfg, 5, frames, latent, latent)["total"]) / 4
     return {
         "value": round((1.0 / dt) * fl_sample / fl_step, 6), "unit": "steps/s", "cores": cores, "kind": "port",
-        "sample": f"mean of 2 oracle UNet steps (oracle/unet_ref.py, fp32 PyTorch CPU ops) at B=1, F={frames}, {sample_hw}x{sample_hw} latents "
+        "sample": f"mean of 3 oracle UNet steps (oracle/unet_ref.py, fp32 PyTorch CPU ops) at B=1, F={frames}, {sample_hw}x{sample_hw} latents "
                   f"= {fl_sample / 1e12:.2f} TFLOP in {dt:.1f} s; scaled by FLOPs to the job-mix step ({fl_step / 1e12:.2f} TFLOP)",
         "sample_seconds": round(dt, 2),
     }
