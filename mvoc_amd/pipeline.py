@@ -208,13 +208,17 @@ class I2VGenXLPipeline:
         st = {"latents": latents.clone(), "t": torch.zeros(1, dtype=torch.float32, device=self.device),
               "coef": torch.zeros(5, dtype=torch.float32, device=self.device)}
         do_cfg = guidance_scale > 1
+        # loop-invariant conditioning (context tokens, cross-attention K/V, image-latent stem): once per loop, not per step
+        shape = (2 if do_cfg else 1,) + tuple(latents.shape[1:])
+        prepared = self.unet.prepare_conditioning(shape, cond["fps"], cond["image_latents"], cond["image_latents"],
+                                                  cond["image_embeddings"], cond["encoder_hidden_states"], False)
 
         def body():
             x = st["latents"]
             inp = torch.cat([x, x]) if do_cfg else x
             noise = self.unet.forward(inp, st["t"], cond["fps"], image_latents=cond["image_latents"],
                                       image_embeddings=cond["image_embeddings"],
-                                      encoder_hidden_states=cond["encoder_hidden_states"])[0]
+                                      encoder_hidden_states=cond["encoder_hidden_states"], conditioning=prepared)[0]
             if do_cfg:
                 ops.ddim_step(x, noise[1:2].contiguous(), st["coef"], v_uncond=noise[0:1].contiguous(), out=x)
             else:
@@ -295,12 +299,17 @@ class I2VGenXLPipeline:
               "fusion_masks": torch.stack([m[0].to(dev, H16) for m in masks]).contiguous(),
               "fusion_objs": torch.empty((n_obj,) + tuple(latents.shape), dtype=H16, device=dev)}
 
+        prepared = self.unet.prepare_conditioning(tuple(st["inp"].shape), cond["fps"], cond["image_latents_first"],
+                                                  cond["image_latents"], cond["image_embeddings"],
+                                                  cond["encoder_hidden_states"], False)
+
         def body():
             x = st["latents"]
             st["inp"][nb - 2].copy_(x[0])
             st["inp"][nb - 1].copy_(x[0])
             noise = self.unet.forward_ext(st["inp"], st["t"], cond["fps"], cond["image_latents_first"], cond["image_latents"],
-                                          cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False)[0]
+                                          cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False,
+                                          conditioning=prepared)[0]
             ops.ddim_step(x, noise[nb - 1:nb].contiguous(), st["coef"], v_uncond=noise[nb - 2:nb - 1].contiguous(), out=x)
 
         st["body"] = body

@@ -206,7 +206,11 @@ class Transformer2DModel(_TransformerBase):
         h = blk.attn1.to_out(a, resid=h)
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
         q2 = blk.attn2.to_q.call_ln(h, blk.norm2)
-        kv = blk.attn2.to_kv(ctx.tokens)
+        kv = ctx.kv.get(self)
+        if kv is None:
+            kv = blk.attn2.to_kv(ctx.tokens)
+            if ctx.keep:
+                ctx.kv[self] = kv
         a = ops.flash_attn(q2, kv[:, :c], kv[:, c:], nbatch=nimg, heads=self.heads, tq=hw, tk=ctx.length,
                            kv_bdiv=ctx.frames_per_ctx)
         h = blk.attn2.to_out(a, resid=h)
@@ -362,6 +366,17 @@ class ConvOut(Hookable):
 class Context:
     def __init__(self, tokens, length, frames_per_ctx):
         self.tokens, self.length, self.frames_per_ctx = tokens, length, frames_per_ctx
+        self.kv = {}       # Transformer2DModel -> cross-attention K|V projection of `tokens` (filled when `keep`)
+        self.keep = False
+
+
+class Conditioning:
+    """Everything of a forward that depends only on the conditioning inputs, not on the noisy sample or the timestep
+    (``I2VGenXLUNet.prepare_conditioning``): context tokens (``pipeline_i2vgen_xl.py:204-260``), every spatial
+    transformer's cross-attention K/V of them, and the image-latent half of the stem (``:262-284``)."""
+
+    def __init__(self, ctx, stem8, geometry, frames, key):
+        self.ctx, self.stem8, self.geometry, self.frames, self.key = ctx, stem8, geometry, frames, key
 
 
 class I2VGenXLUNet:
@@ -622,22 +637,67 @@ class I2VGenXLUNet:
         return Context(ctx.view(B * nf * L, -1), L, 1 if multi_frame_guidance else F)
 
     def forward(self, sample, timestep, fps, image_latents, image_embeddings=None, encoder_hidden_states=None,
-                cross_attention_kwargs=None, return_dict=True, **_):
-        out = self._forward(sample, timestep, fps, image_latents, image_latents, image_embeddings, encoder_hidden_states, False)
+                cross_attention_kwargs=None, return_dict=True, conditioning=None, **_):
+        out = self._forward(sample, timestep, fps, image_latents, image_latents, image_embeddings, encoder_hidden_states, False,
+                            conditioning)
         return (out,)
 
     __call__ = forward
 
     def forward_ext(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings=None,
                     encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
-                    multi_frame_guidance=False, return_dict=True):
+                    multi_frame_guidance=False, return_dict=True, conditioning=None):
         out = self._forward(sample, timestep, fps, image_latents_first, image_latents, image_embeddings,
-                            encoder_hidden_states, multi_frame_guidance)
+                            encoder_hidden_states, multi_frame_guidance, conditioning)
         return (out,)
+
+    # ---- loop-invariant part of a forward ------------------------------------------------------------------
+    def _conditioning(self, shape, image_latents_first, image_latents, image_embeddings, encoder_hidden_states,
+                      multi_frame_guidance, keep=False):
+        """context tokens + the image-latent half of the stem for a sample of ``shape`` [B,4,F,h,w]"""
+        B, C, F, H, W = shape
+        hw = H * W
+        sh = self.shard
+        f0, f1 = (0, F) if sh is None else sh.frame_range(F)
+        if sh is not None:
+            sh.check(F, hw)
+        if sh is not None and multi_frame_guidance:  # per-frame context: this rank's frames only
+            ie = image_embeddings if image_embeddings.dim() == 2 else image_embeddings[:, f0:f1]
+            ctx = self._context(image_latents[:, :, f0:f1], ie, encoder_hidden_states, f1 - f0, True)
+        else:  # one context per sample, built from frame 0 of the full clip
+            ctx = self._context(image_latents, image_embeddings, encoder_hidden_states, f1 - f0, multi_frame_guidance)
+        ctx.keep = keep
+        # stem, image-latent half: image_latents_proj_in -> frame-axis encoder -> channels 4..7 of the conv_in input
+        il = torch.empty((B * F * hw, 4), dtype=H16, device=self.device)
+        ops.ncfhw_to_tokens(image_latents_first.to(self.device, H16), il)
+        for i, (w_, b_) in enumerate(self.proj_in_convs):
+            il, _, _ = ops.conv3x3_small(il, w_, b_, nimg=B * F, h=H, wd=W, cin=w_.shape[3], cout=w_.shape[0], silu=i < 2)
+        stem8 = torch.empty((B * F * hw, 8), dtype=H16, device=self.device)  # channels 0..3: the sample, per step
+        ops.temporal_encoder4(il, self.enc4_params, stem8, b=B, f=F, hw=hw, coff=4)
+        return Conditioning(ctx, stem8, (B, F, H, W), (f0, f1), None)
+
+    def prepare_conditioning(self, sample_shape, fps, image_latents_first, image_latents, image_embeddings=None,
+                             encoder_hidden_states=None, multi_frame_guidance=False):
+        """Hoist the loop-invariant work of a denoising loop out of its iterations: returns a
+        ``Conditioning`` to pass as ``conditioning=`` to ``forward`` / ``forward_ext`` for as long as these inputs (and
+        the frame shard) stay the same.  Per step this removes the context convs / embeddings, the 16 cross-attention K/V
+        projections of the context and the image-latent stem (``fps`` is part of the time embedding and stays per step)."""
+        if not self._loaded:
+            raise RuntimeError("I2VGenXLUNet: load_state_dict() or init_random() first")
+        cond = self._conditioning(tuple(sample_shape), image_latents_first, image_latents, image_embeddings,
+                                  encoder_hidden_states, multi_frame_guidance, keep=True)
+        for tr in self.spatial_transformers():
+            cond.ctx.kv[tr] = tr.transformer_blocks[0].attn2.to_kv(cond.ctx.tokens)
+        cond.key = (tuple(sample_shape), bool(multi_frame_guidance), id(self.shard))
+        return cond
+
+    def spatial_transformers(self):
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            yield from blk.attentions
 
     @torch.no_grad()
     def _forward(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings, encoder_hidden_states,
-                 multi_frame_guidance):
+                 multi_frame_guidance, conditioning=None):
         if not self._loaded:
             raise RuntimeError("I2VGenXLUNet: load_state_dict() or init_random() first")
         cfg = self.config
@@ -648,26 +708,21 @@ class I2VGenXLUNet:
         forward_upsample_size = any(s % up_factor != 0 for s in (H, W))
         temb_act = self._embeddings(timestep, fps, B)
         sh = self.shard
-        f0, f1 = (0, F) if sh is None else sh.frame_range(F)
-        if sh is not None:
-            sh.check(F, hw)
-        if sh is not None and multi_frame_guidance:  # per-frame context: this rank's frames only
-            ie = image_embeddings if image_embeddings.dim() == 2 else image_embeddings[:, f0:f1]
-            ctx = self._context(image_latents[:, :, f0:f1], ie, encoder_hidden_states, f1 - f0, True)
-        else:  # one context per sample, built from frame 0 of the full clip
-            ctx = self._context(image_latents, image_embeddings, encoder_hidden_states, f1 - f0, multi_frame_guidance)
+        if conditioning is None:
+            conditioning = self._conditioning((B, C, F, H, W), image_latents_first, image_latents, image_embeddings,
+                                              encoder_hidden_states, multi_frame_guidance)
+        elif conditioning.key != ((B, C, F, H, W), bool(multi_frame_guidance), id(sh)):
+            raise RuntimeError(f"conditioning was prepared for {conditioning.key}, this call is "
+                               f"{((B, C, F, H, W), bool(multi_frame_guidance), id(sh))}")
+        ctx = conditioning.ctx
+        f0, f1 = conditioning.frames
 
-        # stem: image_latents_proj_in -> temporal encoder -> cat with sample -> conv_in -> transformer_in
-        il = torch.empty((B * F * hw, 4), dtype=H16, device=self.device)
-        ops.ncfhw_to_tokens(image_latents_first.to(self.device, H16), il)
-        for i, (w_, b_) in enumerate(self.proj_in_convs):
-            il, _, _ = ops.conv3x3_small(il, w_, b_, nimg=B * F, h=H, wd=W, cin=w_.shape[3], cout=w_.shape[0], silu=i < 2)
-        x8 = torch.empty((B * F * hw, 8), dtype=H16, device=self.device)
+        # stem: [sample | encoded image latents] -> conv_in -> transformer_in
+        x8 = conditioning.stem8.clone() if conditioning.key is not None else conditioning.stem8  # cached: keep the template
         ops.ncfhw_to_tokens(sample, x8, coff=0)
-        ops.temporal_encoder4(il, self.enc4_params, x8, b=B, f=F, hw=hw, coff=4)
         if sh is not None:
-            # the 4-channel stem above (three small convs + the frame-axis encoder) is computed for the whole clip on
-            # every rank -- 0.01 % of the step; from conv_in on, the rank holds only its own frames
+            # the 4-channel stem (three small convs + the frame-axis encoder) is computed for the whole clip on every
+            # rank -- 0.01 % of the step; from conv_in on, the rank holds only its own frames
             x8 = x8.view(B, F, hw, 8)[:, f0:f1].reshape(-1, 8)
             F = f1 - f0
         geo = (B, F, H, W)

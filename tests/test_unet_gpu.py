@@ -129,3 +129,24 @@ def test_missing_weights_fail_loudly():
                     torch.zeros(1, 7, 64))
     with pytest.raises(KeyError):
         eng.load_state_dict({})
+
+
+@pytest.mark.parametrize("mfg", [False, True])
+def test_prepared_conditioning_is_bit_identical(pair, mfg):
+    """hoisting the loop-invariant work (context tokens, cross-attention K/V, image-latent stem) out of the step must
+    not change a bit; a conditioning prepared for another shape is refused"""
+    _, eng = pair
+    g = torch.Generator().manual_seed(11)
+    b, f, h, w = 2, 4, 16, 16
+    r = lambda *s: torch.randn(*s, generator=g).half().cuda()
+    x, first, lat, emb, ehs = r(b, 4, f, h, w), r(b, 4, f, h, w), r(b, 4, f, h, w), r(b, f, 64), r(b, 7, 64)
+    fps = torch.full((b,), 8.0).cuda()
+    prep = eng.prepare_conditioning((b, 4, f, h, w), fps, first, lat, emb, ehs, mfg)
+    for t in (981.0, 501.0):
+        tt = torch.tensor([t]).cuda()
+        ref = eng.forward_ext(x, tt, fps, first, lat, emb, ehs, multi_frame_guidance=mfg)[0]
+        got = eng.forward_ext(x, tt, fps, first, lat, emb, ehs, multi_frame_guidance=mfg, conditioning=prep)[0]
+        assert torch.equal(ref, got)
+        x = r(b, 4, f, h, w)  # the template must survive a step with another sample
+    with pytest.raises(RuntimeError):
+        eng.forward_ext(x[:1], tt, fps[:1], first[:1], lat[:1], emb[:1], ehs[:1], multi_frame_guidance=mfg, conditioning=prep)
