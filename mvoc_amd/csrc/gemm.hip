@@ -879,37 +879,39 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   int model_sk = 0;
   if (tile == 0 && glds_ok) {
     const bool stats_precomputed = !(d->ln_rowsum && !d->ln_stats);
-    if (d->k <= 640 && d->m > 2048 && stats_precomputed) {
+    if (d->k <= 640 && d->m > 2048 && stats_precomputed && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {
       // five to ten K steps: the launch is prologue / epilogue bound, not MFMA bound -- K step 32 halves the LDS per
       // block so four (128x128) or three (160x128) blocks share a CU and hide each other's ramps: 10-20 % faster here
       tile = (d->act == MVOC_ACT_GEGLU || d->n % 128 == 0 || d->n > 320 || d->n % 160) ? 61 : 62;
     } else if (d->act == MVOC_ACT_GEGLU) {
-      // measured (tools/gemm_bench.py): 128x256 tiles win from 16 K rows up (the K-step-32 one needs precomputed LN statistics)
-      const bool stats_in_kernel = d->ln_rowsum && !d->ln_stats;
-      tile = d->m >= 16384 ? (stats_in_kernel ? 15 : 65) : 11;
+      // measured (tools/gemm_bench.py): 256-row tiles win from 16 K rows up (the K-step-32 ones need precomputed LN statistics)
+      tile = d->m >= 16384 ? (!stats_precomputed ? 15 : d->n % 256 == 0 ? 67 : 65) : 11;
     } else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) {
       tile = 13;  // few rows and no split-K: many small blocks (latency-bound regime, outside the model below)
     } else {
       // Pick the tile by a wave-quantisation cost model calibrated on MI355X (tools/gemm_bench.py, B = 1 and B = 5 shape
-      // sets): a launch runs in "waves" of `slots` resident blocks (2 per CU); a
-      // partly filled last wave costs 0.3 + 0.7 * fill of a full one; a block costs bm * bn * k_slice / eff.
-      static const struct { int tile, bn, bm, slots; float eff; } cand[] = {
-          {12, 160, 128, 512, 1.00f}, {11, 128, 128, 512, 0.94f}, {64, 160, 256, 512, 1.05f}};
+      // sets).  The K loop is bound by the L2 -> LDS fill rate (~70 GB/s per CU), so a tile's chip-wide rate grows with
+      // its flop per staged byte: `rate` = TFLOP/s it sustains when the grid fills the chip.  A launch runs in "waves" of
+      // `slots` resident blocks; a partly filled last wave costs 0.3 + 0.7 * fill of a full one (a full one for the 8-wave tiles).
+      static const struct { int tile, bn, bm, slots; float rate; } cand[] = {
+          {12, 160, 128, 512, 950.f}, {11, 128, 128, 512, 890.f}, {64, 160, 256, 512, 1090.f},
+          {66, 320, 256, 256, 1170.f}, {67, 256, 256, 256, 1020.f}};
       const bool can_split = d->workspace && d->split_k == 0 && !d->ln_rowsum;
       double best = 0;
       for (const auto& c : cand) {
         if (d->n % c.bn) continue;
-        if (c.tile == 64 && (d->m < 65536 || d->k < 4096 || (d->ln_rowsum && !d->ln_stats))) continue;
+        if (c.bm == 256 && (d->m < 65536 || !stats_precomputed)) continue;  // measured: below 64 K rows their tails cost more than the model says
         const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn);
         int sk = 1;
-        if (can_split && blocks < 384)
+        if (can_split && blocks < 384 && c.bm == 128)
           while (sk < 8 && blocks * sk < 512 && d->k % (64 * sk * 2) == 0 && d->k / (sk * 2) >= 512) sk *= 2;
         if (sk > 1 && (size_t)sk * d->m * d->n * 4 > d->workspace_bytes) sk = 1;
         const double w = (double)(blocks * sk) / c.slots;
         const double full = (double)(long)w, frac = w - full;
-        const double waves = full + (frac > 0 ? 0.3 + 0.7 * frac : 0.0);
-        double cost = waves * 2.0 * c.bm * c.bn * (double)(d->k / sk) / (1.66e6 * c.eff);      // us
-        if (sk > 1) cost += 5.0 + 2.0 * sk * (double)d->m * d->n * 4.0 / 3.0e6;                // fp32 slabs + reduce pass
+        // one block per CU (8-wave tiles): a partial wave costs a full one; two per CU: the survivors run faster alone
+        const double waves = full + (frac > 0 ? (c.slots == 256 ? 1.0 : 0.3 + 0.7 * frac) : 0.0);
+        double cost = waves * c.slots * 2.0 * c.bm * c.bn * (double)(d->k / sk) / (c.rate * 1e6);  // us
+        if (sk > 1) cost += 5.0 + 2.0 * sk * (double)d->m * d->n * 4.0 / 3.0e6;                    // fp32 slabs + reduce pass
         if (tile == 0 || cost < best) { best = cost; tile = c.tile; model_sk = sk; }
       }
       if (tile == 0) tile = 13;  // n is a multiple of neither 160 nor 128
@@ -923,8 +925,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
-    const int bm = tile == 14 || tile == 64 || tile % 10 == 5 ? 256 : 128;
-    const int bn = (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);  // x1: 128, x2: 160, x3: 64
+    const int bm = tile == 14 || tile == 64 || tile == 66 || tile == 67 || tile % 10 == 5 ? 256 : 128;
+    const int bn = tile == 66 ? 320 : tile == 67 ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (model_sk > 0) {
@@ -1003,6 +1005,14 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 65:
       MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 65 needs k, cin, c1 %% 64 == 0 and row statistics");
       return launch_glds<1, 4, 4, 2, 2, 0, 32>(a, s);  // 128 x 256
+    // 8 waves, 64-row-per-wave register tiles: the highest flop per L2 byte (the K loop is bound by the L2 -> LDS fill rate)
+    case 66:
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
+                   "gemm: tile 66 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
+      return launch_glds<2, 4, 5, 2, 2, 0, 32>(a, s);  // 320 x 256
+    case 67:
+      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 67 needs k, cin, c1 %% 64 == 0 and row statistics");
+      return launch_glds<2, 4, 4, 2, 2, 0, 32>(a, s);  // 256 x 256
     case 52:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 52 needs k, cin, c1 %% 64 == 0 and no GEGLU");
       return launch_glds<1, 4, 5, 1, 2, 2>(a, s);  // 160 x 128 with s_setprio around the MFMA clusters

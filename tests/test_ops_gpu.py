@@ -35,7 +35,7 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 21, 22, 23, 61, 62, 63, 64, 65])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 21, 22, 23, 61, 62, 63, 64, 65, 66, 67])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
