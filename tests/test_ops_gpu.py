@@ -499,3 +499,28 @@ def test_temporal_encoder4_and_layout(ops):
     assert rel_l2(out[:, 4:].reshape(b, f, hw, 4), ref) < 3e-3
     back = ops.tokens_to_ncfhw(out[:, 4:].contiguous(), b, 4, f, hw, 1)
     assert torch.equal(back.cpu()[..., 0].permute(0, 2, 3, 1), out[:, 4:].cpu().reshape(b, f, hw, 4))
+
+
+@pytest.mark.parametrize("nobj", [1, 3, 4])
+@pytest.mark.parametrize("bg", [False, True])
+def test_pnp_tokens_n_objects_bit_exact(ops, nobj, bg):
+    """the batch layout [bg, obj_1..obj_n, uncond, cond] for n != 2 (the reference hard-codes 5 chunks,
+    ``pnp_utils.py:592``; the oracle restates the same chain over a list of n masks)"""
+    from oracle import pnp_ref
+    g = torch.Generator().manual_seed(40 + nobj)
+    Fr, H, W, C, nb = 2, 6, 5, 64, nobj + 3
+    q = torch.randn(nb * Fr, H * W, C, generator=g).half()
+    k = torch.randn(nb * Fr, H * W, C, generator=g).half()
+    hard = torch.rand(nobj, Fr, 12, 10, generator=g) > 0.5
+    rq, rk = pnp_ref.inject_qk_spatial(q, k, [hard[j] for j in range(nobj)], Fr, H, W, inject_background=bg)
+    dq, dk = dev(q), dev(k)
+    ops.pnp_blend_tokens(dq, dev(hard.half()), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=Fr * H * W * C,
+                         f_stride=H * W * C, p_stride=C, base_chunk0=bg)
+    assert torch.equal(bits(dq), bits(rq)) and torch.equal(bits(dk), bits(rk))
+    # feature form
+    x = torch.randn(nb * Fr, 24, H, W, generator=g).half()
+    hard2 = torch.rand(nobj, Fr, H, W, generator=g) > 0.5
+    ref = pnp_ref.inject_feature_nchw(x, [hard2[j] for j in range(nobj)])
+    dx = dev(x)
+    ops.pnp_blend_nchw(dx, dev(hard2.half()), frames=Fr, base_chunk0=True)
+    assert torch.equal(bits(dx), bits(ref))
