@@ -167,10 +167,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 // row-add vectors are per channel there: broadcast loads), the fp16-rounded result is parked in a wave-private LDS
 // tile [32 pixels][TO*32 channels] (pitch + 16 B: conflict-free 8-byte writes), read back as 16-byte row chunks, the
 // residual added, stored.  `lds` = this wave's region (32 * (TO*64+16) bytes), free once every wave left the K loop.
-template <int WN, int WM, int TN, int TM>
+template <int WN, int WM, int TN, int TM, bool GEGLU>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&acc)[TN][TM], int n0, int m0, int wn, int wm,
                                                   int r, int h, int lane, char* lds, const float* lnstat) {
-  const bool geglu = p.act == MVOC_ACT_GEGLU;
+  constexpr bool geglu = GEGLU;
+  constexpr int TO = GEGLU ? TN / 2 : TN;  // 32-channel output tiles per wave
   const bool use_bias = p.bias && !lnstat;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
@@ -183,10 +184,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&ac
       ln_mu = lnstat[2 * (mrow + r)];
       ln_rs = lnstat[2 * (mrow + r) + 1];
     }
-    int TO = TN;
-    if (geglu) {
+    if constexpr (geglu) {
       if constexpr (TN % 2 == 0) {
-        TO = TN / 2;
         const int pitch = TO * 64 + 16;
 #pragma unroll
         for (int i = 0; i < TN; i += 2) {
@@ -261,19 +260,37 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&ac
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (DS ops of a wave execute in order)
     // ---- read back as rows: chunk = 8 consecutive channels (16 B) of one pixel ---------------------------
-    const int nchunk = 4 * TO, pitch = TO * 64 + 16;
+    // in batches of NB chunks per lane: the batch's LDS reads and residual loads are issued before its first add
+    // (NB = 2 keeps the 160-wide tiles at their register budget; a full unroll cost 40-70 VGPRs and an occupancy step)
+    constexpr int nchunk = 4 * TO, pitch = TO * 64 + 16;
+    constexpr int NIT = (32 * nchunk + 63) / 64;
+    constexpr int NB = NIT <= 4 ? NIT : 2;
     const int nbase = geglu ? (n0 + wn * TN * 32) / 2 : n0 + wn * TN * 32;
-    for (int idx = lane; idx < 32 * nchunk; idx += 64) {
-      const int px = idx / nchunk, c = idx - px * nchunk;
-      const int m = m0 + mrow + px, n = nbase + c * 8;
-      if (m >= p.M || n >= p.n_store) continue;
-      half8_t v = *reinterpret_cast<const half8_t*>(lds + px * pitch + c * 16);
-      if (p.resid) {
-        const half8_t r8 = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += NB) {
+      half8_t v[NB], r8[NB];
+      bool on[NB];
+      size_t orow[NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
+      for (int u = 0; u < NB; ++u) {
+        const int idx = lane + (it0 + u) * 64;
+        const int px = idx / nchunk, c = idx - px * nchunk;
+        const int m = m0 + mrow + px, n = nbase + c * 8;
+        on[u] = it0 + u < NIT && idx < 32 * nchunk && m < p.M && n < p.n_store;
+        orow[u] = (size_t)m * p.ldo + n;
+        v[u] = *reinterpret_cast<const half8_t*>(lds + (on[u] ? px * pitch + c * 16 : 0));
+        if (p.resid && on[u]) r8[u] = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
       }
-      *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (!on[u]) continue;
+        half8_t o = v[u];
+        if (p.resid) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)r8[u][e]);
+        }
+        *reinterpret_cast<half8_t*>(p.out + orow[u]) = o;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next j overwrites the tile
   }
@@ -732,8 +749,12 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   {
     if (p.epi_lds && !(p.ln_s && !p.ln_stats)) {
       __syncthreads();  // every wave is out of the K loop: the staging buffers are free
-      gemm_epilogue_lds<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES,
-                                        p.ln_s ? p.ln_stats + 2 * (size_t)m0 : nullptr);
+      const float* st = p.ln_s ? p.ln_stats + 2 * (size_t)m0 : nullptr;
+      if (p.act == MVOC_ACT_GEGLU) {
+        if constexpr (TN % 2 == 0) gemm_epilogue_lds<WN, WM, TN, TM, true>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES, st);
+      } else {
+        gemm_epilogue_lds<WN, WM, TN, TM, false>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES, st);
+      }
       return;
     }
   }
