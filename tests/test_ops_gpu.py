@@ -524,3 +524,44 @@ def test_pnp_tokens_n_objects_bit_exact(ops, nobj, bg):
     dx = dev(x)
     ops.pnp_blend_nchw(dx, dev(hard2.half()), frames=Fr, base_chunk0=True)
     assert torch.equal(bits(dx), bits(ref))
+
+
+@pytest.mark.parametrize("tile", [111, 112, 164, 166])
+@pytest.mark.parametrize("shape", [(3, 64, 320, 9, 7), (2, 128, 320, 16, 16), (5, 64, 640, 5, 33), (1, 64, 160, 3, 3), (2, 192, 320, 40, 8)])
+def test_conv3x3_tap_reuse(ops, tile, shape):
+    """conv_dx_kernel: the three kx taps of a (ky, chunk) share one staged block of consecutive pixels; image / row
+    borders are masked on the fragments.  Shapes cross image boundaries inside one M tile (n*h*w not a multiple of the
+    tile, rows narrower and wider than the tile), with a residual and a time-embedding row add."""
+    from mvoc_amd.unet import pack_conv3x3
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + tile)
+    x = torch.randn(n, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half()
+    b = torch.randn(cout, generator=g).half()
+    res = torch.randn(n, cout, h, w, generator=g).half()
+    ref = F.conv2d(x.float(), wt.float(), b.float(), padding=1).half().float() + res.float()
+    out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, n_store=cout, tile=tile,
+                              resid=dev(_nhwc(res)))
+    assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
+    # exact-integer check of the border masks: all-ones input and weights count the valid taps of every pixel
+    xi = torch.ones(n, cin, h, w).half()
+    wi = torch.zeros(cout, cin, 3, 3).half()
+    wi[:, :8] = 1.0 / 8
+    refi = F.conv2d(xi.float(), wi.float(), None, padding=1)
+    outi, _, _ = ops.conv3x3(dev(_nhwc(xi)), pack_conv3x3(dev(wi)), dev(torch.zeros(cout).half()), nimg=n, h=h, wd=w,
+                             n_store=cout, tile=tile)
+    assert torch.equal(_from_rows(outi, n, h, w).float().cpu(), refi)
+
+
+def test_conv3x3_tap_reuse_two_sources(ops):
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(77)
+    n, c1, c2, cout, h, w = 3, 128, 64, 160, 12, 10
+    x1, x2 = torch.randn(n, c1, h, w, generator=g).half(), torch.randn(n, c2, h, w, generator=g).half()
+    wt = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / 40).half()
+    b = torch.randn(cout, generator=g).half()
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), wt.float(), b.float(), padding=1)
+    for tile in (0, 112):
+        out, _, _ = ops.conv3x3(dev(_nhwc(x1)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, x2=dev(_nhwc(x2)), n_store=cout,
+                                tile=tile)
+        assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
