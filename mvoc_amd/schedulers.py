@@ -20,12 +20,18 @@ import torch
 from . import ops
 
 
+def _sqrt32(t):
+    """correctly rounded fp32 square root: ``torch.sqrt`` on CPU differs by an ulp between hosts (vectorised kernel), which
+    made the schedule tables host-dependent; numpy's is IEEE, like CUDA's sqrtf on the reference's platform"""
+    return torch.from_numpy(np.asarray(np.sqrt(torch.as_tensor(t, dtype=torch.float32).detach().cpu().numpy())))
+
+
 def _alphas_cumprod(n=1000):
     def bar(t):
         return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
 
     betas = torch.tensor([min(1 - bar((i + 1) / n) / bar(i / n), 0.999) for i in range(n)], dtype=torch.float32)
-    root = torch.cumprod(1.0 - betas, dim=0).sqrt()
+    root = _sqrt32(torch.cumprod(1.0 - betas, dim=0))
     r0, rT = root[0].clone(), root[-1].clone()
     root = (root - rT) * (r0 / (r0 - rT))
     ab = root ** 2
@@ -97,7 +103,7 @@ class DDIMScheduler:
 
     def coefficients(self, t, guidance_scale=1.0):
         a_from, a_to = self._alphas_for(int(t))
-        return [float(a_from ** 0.5), float((1 - a_from) ** 0.5), float(a_to ** 0.5), float((1 - a_to) ** 0.5),
+        return [float(_sqrt32(a_from)), float(_sqrt32(1 - a_from)), float(_sqrt32(a_to)), float(_sqrt32(1 - a_to)),
                 float(np.float32(guidance_scale))]
 
     def coef_table(self, device, guidance_scale=1.0):

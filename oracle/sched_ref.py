@@ -19,6 +19,13 @@ import numpy as np
 import torch
 
 
+def _sqrt32(t: torch.Tensor) -> torch.Tensor:
+    """correctly rounded fp32 square root (what CUDA's sqrtf / ``tensor ** 0.5`` gives on the reference's platform).
+    ``torch.sqrt`` on CPU is NOT bit-reproducible across hosts (the vectorised kernel differs by an ulp between the build
+    container and the GPU box), which moved ``alphas_cumprod[1]`` by 2 ulp; numpy's is IEEE."""
+    return torch.from_numpy(np.asarray(np.sqrt(t.detach().to(torch.float32).cpu().numpy())))
+
+
 def make_alphas_cumprod(num_train_timesteps=1000, rescale_zero_snr=True) -> torch.Tensor:
     def alpha_bar(t):
         return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
@@ -29,7 +36,7 @@ def make_alphas_cumprod(num_train_timesteps=1000, rescale_zero_snr=True) -> torc
         betas.append(min(1 - alpha_bar(t2) / alpha_bar(t1), 0.999))
     betas = torch.tensor(betas, dtype=torch.float32)
     if rescale_zero_snr:
-        ab_sqrt = torch.cumprod(1.0 - betas, dim=0).sqrt()
+        ab_sqrt = _sqrt32(torch.cumprod(1.0 - betas, dim=0))
         s0, sT = ab_sqrt[0].clone(), ab_sqrt[-1].clone()
         ab_sqrt = (ab_sqrt - sT) * (s0 / (s0 - sT))
         ab = ab_sqrt ** 2
@@ -77,10 +84,10 @@ class DDIMSchedulerRef:
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
-        x0 = _smul(a_t ** 0.5, sample) - _smul(b_t ** 0.5, model_output)
-        eps = _smul(a_t ** 0.5, model_output) + _smul(b_t ** 0.5, sample)
-        direction = _smul((1 - a_prev) ** 0.5, eps)
-        return _Out(_smul(a_prev ** 0.5, x0) + direction)
+        x0 = _smul(_sqrt32(a_t), sample) - _smul(_sqrt32(b_t), model_output)
+        eps = _smul(_sqrt32(a_t), model_output) + _smul(_sqrt32(b_t), sample)
+        direction = _smul(_sqrt32((1 - a_prev)), eps)
+        return _Out(_smul(_sqrt32(a_prev), x0) + direction)
 
 
 class DDIMInverseSchedulerRef(DDIMSchedulerRef):
@@ -100,7 +107,7 @@ class DDIMInverseSchedulerRef(DDIMSchedulerRef):
         a_cur = self.alphas_cumprod[cur] if cur >= 0 else self.initial_alpha_cumprod
         a_nxt = self.alphas_cumprod[nxt]
         b_cur = 1 - a_cur
-        x0 = _smul(a_cur ** 0.5, sample) - _smul(b_cur ** 0.5, model_output)
-        eps = _smul(a_cur ** 0.5, model_output) + _smul(b_cur ** 0.5, sample)
-        direction = _smul((1 - a_nxt) ** 0.5, eps)
-        return _Out(_smul(a_nxt ** 0.5, x0) + direction)
+        x0 = _smul(_sqrt32(a_cur), sample) - _smul(_sqrt32(b_cur), model_output)
+        eps = _smul(_sqrt32(a_cur), model_output) + _smul(_sqrt32(b_cur), sample)
+        direction = _smul(_sqrt32((1 - a_nxt)), eps)
+        return _Out(_smul(_sqrt32(a_nxt), x0) + direction)

@@ -165,3 +165,102 @@ def test_g9_mask_fixture_shapes(golden_dir):
         # bool = (u8 > 10) as the reference's cv2.threshold(…, 10, 255) does
         assert np.array_equal(g[f"{name}_64x64_bool"], g[f"{name}_64x64_float_u8"] > 10)
         assert g[f"{name}_64x64_bool"].any()
+
+
+# ---- G8: the three loops as run by the reference's own pipeline methods ---------------------------------------------
+def _g8_unet_fn(calls, seen):
+    """the loop restatements call ``unet_fn(x, t)``: conditioning as the reference assembled it (identical at every step),
+    the UNet = the fixture's fake; every input batch is checked against what the reference's loop fed at that step"""
+    from g8_common import fake_unet
+
+    def fn(x, t):
+        i = len(seen)
+        assert int(t) == calls.t[i]
+        assert torch.equal(x, calls.x[i]), f"step {i}: UNet input differs from the reference loop's"
+        seen.append(int(t))
+        return fake_unet(x, t, calls.ehs[i], calls.fps[i], calls.ilf[i], calls.il[i], calls.ie[i])
+    return fn
+
+
+@pytest.mark.parametrize("tag,gs", [("inv_cfg1", 1.0), ("inv_cfg75", 7.5)])
+def test_g8_invert_loop_matches_reference(golden_dir, tag, gs):
+    from g8_common import Calls
+    from oracle import loops_ref, sched_ref
+    g = _load(golden_dir, "g8_loops.npz")
+    calls, seen = Calls(g, tag), []
+    x0 = torch.from_numpy(g[f"{tag}_x0"])
+    saved, seq = loops_ref.invert_loop(_g8_unet_fn(calls, seen), sched_ref.DDIMInverseSchedulerRef(), x0, 4, gs)
+    assert len(seen) == calls.n == 4
+    assert torch.equal(seq, torch.from_numpy(g[f"{tag}_out"]))  # [1, steps, 4, F, h, w], noisiest first
+    # files: ddim_latents_{t}.pt holds the latent AT noise level t
+    files = [str(f) for f in g[f"{tag}_files"]]
+    assert files == sorted(f"ddim_latents_{t}.pt" for t in saved)
+    for f, lat in zip(files, g[f"{tag}_file_latents"]):
+        assert torch.equal(saved[int(f.split("_")[-1][:-3])], torch.from_numpy(lat))
+
+
+def test_g8_sample_loop_matches_reference(golden_dir):
+    from g8_common import Calls
+    from oracle import loops_ref, sched_ref
+    g = _load(golden_dir, "g8_loops.npz")
+    calls, seen = Calls(g, "call"), []
+    out = loops_ref.sample_loop(_g8_unet_fn(calls, seen), sched_ref.DDIMSchedulerRef(), torch.from_numpy(g["call_xT"]), 4, 9.0,
+                                ddim_init_latents_t_idx=1)
+    assert seen == [501, 251, 1]
+    assert torch.equal(out, torch.from_numpy(g["call_out"]))
+
+
+@pytest.mark.parametrize("tag,kw", [("comp", dict(random_noise_ratio=0.0, obj_random_noise_fusion=False, fusion_steps=(0, 1))),
+                                    ("comp_rnf", dict(random_noise_ratio=0.3, obj_random_noise_fusion=True, fusion_steps=(0, 2)))])
+def test_g8_composition_loop_matches_reference(golden_dir, tag, kw):
+    """fusion arithmetic, [bg, obj1, obj2, latents, latents] assembly, CFG on the last two chunks, DDIM update, the
+    never-incremented fusion counter and the per-object timestep offsets -- against the reference's own loop"""
+    from g8_common import Calls, seeded
+    from oracle import loops_ref, sched_ref
+    g = _load(golden_dir, "g8_loops.npz")
+    calls, seen = Calls(g, tag), []
+    Fr, h, w = int(g["frames"]), int(g["h"]), int(g["w"])
+    lat = lambda key, t: seeded(key * 1000 + int(t), (1, 4, Fr, h, w))  # the ddim_latents_{t}.pt files the generator wrote
+    masks = [torch.from_numpy(m) for m in g[f"{tag}_mask_float"]]
+    hook_ts = []
+    out = loops_ref.composition_loop(_g8_unet_fn(calls, seen), sched_ref.DDIMSchedulerRef(), torch.from_numpy(g[f"{tag}_xT"]),
+                                     lambda t: lat(20, t), lambda j, t: lat(30 + 10 * j, t), masks, 5, guidance_scale=9.0,
+                                     ddim_init_latents_t_idx=1, obj_ddim_latents_idx_offset=[0, 1],
+                                     on_step=lambda i, t: hook_ts.append(t), **kw)
+    assert seen == [601, 401, 201, 1] and hook_ts == calls.hook_t  # register_time_all(t) precedes every UNet call
+    assert torch.equal(out, torch.from_numpy(g[f"{tag}_out"]))
+
+
+def test_g8_reference_conditioning_layout(golden_dir):
+    """what the reference's own prepare_image_latents / _encode_image / batch assembly produce (the layout
+    mvoc_amd.pipeline reproduces): frame-position ramp k/(F-1), zero image embedding for the uncond chunk, and the
+    composition batch order [bg, obj_1, obj_2, main(uncond), main(cond)] for every conditioning tensor"""
+    from g8_common import seeded, prompt_key
+    g = _load(golden_dir, "g8_loops.npz")
+    Fr, h, w, D = int(g["frames"]), int(g["h"]), int(g["w"]), int(g["dim"])
+    il = torch.from_numpy(g["inv_cfg75_il"][0])  # [2,4,F,h,w]: CFG duplicates the image latents
+    first = (seeded(503, (1, 4, h, w)) * 0.18215)
+    assert torch.equal(il[0], il[1]) and torch.equal(il[0, :, 0], first[0])
+    for k in range(1, Fr):
+        assert torch.equal(il[0, :, k], torch.full((4, h, w), k / (Fr - 1)).half())
+    ie = torch.from_numpy(g["inv_cfg75_ie"][0])  # [2,1,D]: zeros for uncond
+    assert not ie[0].any() and torch.equal(ie[1, 0], seeded(303, (1, D))[0])
+    ehs = torch.from_numpy(g["inv_cfg75_ehs"][0])
+    assert torch.equal(ehs[0], seeded(1000 + prompt_key("bad"), (1, 7, D))[0]) and torch.equal(ehs[1], seeded(prompt_key("a boat"), (1, 7, D))[0])
+    # composition: batch of 5
+    ehs = torch.from_numpy(g["comp_ehs"][0])
+    inv = seeded(prompt_key(""), (1, 7, D))[0]
+    assert all(torch.equal(ehs[j], inv) for j in range(3))
+    assert torch.equal(ehs[3], seeded(1000 + prompt_key("chaotic"), (1, 7, D))[0]) and torch.equal(ehs[4], seeded(prompt_key("windsurf"), (1, 7, D))[0])
+    ilf = torch.from_numpy(g["comp_ilf"][0])  # first-frame latents: bg(2), obj(4), obj(5), main(1), main(1)
+    for b, img in enumerate((2, 4, 5, 1, 1)):
+        assert torch.equal(ilf[b, :, 0], (seeded(500 + img, (1, 4, h, w)) * 0.18215)[0])
+    il = torch.from_numpy(g["comp_il"][0])  # image_latents: frame 0 of each list: bg 20, obj 40, obj 50; main = main_first_image
+    for b, img in enumerate((20, 40, 50, 1, 1)):
+        assert torch.equal(il[b, :, 0], (seeded(500 + img, (1, 4, h, w)) * 0.18215)[0])
+    ie = torch.from_numpy(g["comp_ie"][0])  # [5,F,D]: per-frame CLIP embeddings; uncond chunk zero
+    for b, base in ((0, 20), (1, 40), (2, 50), (4, 10)):
+        for f in range(Fr):
+            assert torch.equal(ie[b, f], seeded(300 + base + f, (1, D))[0])
+    assert not ie[3].any()
+    assert torch.equal(torch.from_numpy(g["comp_fps"][0]), torch.tensor([8] * 5))

@@ -231,3 +231,116 @@ def test_dropin_drivers_end_to_end(tmp_path):
     assert sub == ["ddim_init_latents_t_idx_0_nsteps_5_cfg_9.0_pnpf0.2_pnps1.0_pnpt1.0_ratio0.0noise_fusion_step0-1"]
     lat = torch.load(out_root / sub[0] / "video_latents.pt")
     assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
+
+
+# ---- G8: the HIP pipeline's loops against the REFERENCE's own loops (tests/golden/g8_loops.npz) -----------------------
+def _g8_pipe(scheduler):
+    """the tiny HIP engine (attribute tree for the hooks) with its forward replaced by the fixture's elementwise stand-in
+    UNet -- what remains under test is everything else of a loop iteration: conditioning assembly, batch order, latent
+    cache files, fusion / CFG / (inverse-)DDIM kernels"""
+    from g8_common import fake_unet, seeded, prompt_key
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    _, eng = _pair()
+    D = 64
+    calls = []
+
+    def fwd(sample, timestep, fps, image_latents, image_embeddings=None, encoder_hidden_states=None, **kw):
+        calls.append(sample.clone())
+        return (fake_unet(sample, timestep, encoder_hidden_states, fps, image_latents, image_latents, image_embeddings),)
+
+    def fwd_ext(sample, timestep, fps, image_latents_first, image_latents, image_embeddings=None, encoder_hidden_states=None, **kw):
+        calls.append(sample.clone())
+        return (fake_unet(sample, timestep, encoder_hidden_states, fps, image_latents_first, image_latents, image_embeddings),)
+
+    eng.forward, eng.forward_ext = fwd, fwd_ext
+    eng.prepare_conditioning = lambda *a, **k: None
+
+    class Cond:
+        vae_scale_factor, cross_attention_dim = 8, D
+
+        def encode_prompt(self, prompt, negative_prompt=None):
+            return seeded(prompt_key(prompt), (1, 7, D)).cuda(), seeded(1000 + prompt_key(negative_prompt), (1, 7, D)).cuda()
+
+        def encode_image(self, image):
+            return seeded(300 + int(image), (1, D))[None].cuda()
+
+        def image_latents(self, image, num_frames, height, width):
+            h, w = height // 8, width // 8
+            first = (seeded(500 + int(image), (1, 4, h, w)) * 0.18215)[:, :, None]
+            ramp = [torch.full((1, 4, 1, h, w), k / (num_frames - 1)).half() for k in range(1, num_frames)]
+            return torch.cat([first] + ramp, 2).cuda()
+
+    pipe = I2VGenXLPipeline(eng, scheduler, conditioner=Cond(), use_graphs=False)
+    return pipe, calls
+
+
+@pytest.mark.parametrize("tag,gs", [("inv_cfg1", 1.0), ("inv_cfg75", 7.5)])
+def test_g8_hip_invert_matches_reference_loop(golden_dir, tmp_path, tag, gs):
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    g = np.load(os.path.join(golden_dir, "g8_loops.npz"))
+    Fr, h, w = int(g["frames"]), int(g["h"]), int(g["w"])
+    pipe, calls = _g8_pipe(DDIMInverseScheduler())
+    out_dir = str(tmp_path / "lat")
+    seq = pipe.invert(prompt="a boat", image=3, height=h * 8, width=w * 8, target_fps=8, num_frames=Fr, num_inference_steps=4,
+                      guidance_scale=gs, negative_prompt="bad", latents=torch.from_numpy(g[f"{tag}_x0"]).cuda(), return_dict=False,
+                      output_dir=out_dir)
+    for i, x in enumerate(calls):  # the batch fed to the UNet at every step, bit for bit
+        assert torch.equal(x.cpu(), torch.from_numpy(g[f"{tag}_x"][i]))
+    assert torch.equal(seq.cpu(), torch.from_numpy(g[f"{tag}_out"]))
+    for f, lat in zip(g[f"{tag}_files"], g[f"{tag}_file_latents"]):
+        assert torch.equal(torch.load(os.path.join(out_dir, str(f))), torch.from_numpy(lat))
+
+
+def test_g8_hip_call_matches_reference_loop(golden_dir):
+    from mvoc_amd.schedulers import DDIMScheduler
+    g = np.load(os.path.join(golden_dir, "g8_loops.npz"))
+    Fr, h, w = int(g["frames"]), int(g["h"]), int(g["w"])
+    pipe, calls = _g8_pipe(DDIMScheduler())
+    out = pipe(prompt="a boat", image=3, height=h * 8, width=w * 8, target_fps=8, num_frames=Fr, num_inference_steps=4,
+               guidance_scale=9.0, negative_prompt="bad", latents=torch.from_numpy(g["call_xT"]).cuda(), output_type="latent",
+               ddim_init_latents_t_idx=1).frames
+    assert len(calls) == 3 and all(torch.equal(x.cpu(), torch.from_numpy(g["call_x"][i])) for i, x in enumerate(calls))
+    assert torch.equal(out.cpu(), torch.from_numpy(g["call_out"]))
+
+
+@pytest.mark.parametrize("tag,kw", [("comp", dict(random_noise_ratio=0.0, obj_random_noise_fusion=False, fusion_steps=(0, 1))),
+                                    ("comp_rnf", dict(random_noise_ratio=0.3, obj_random_noise_fusion=True, fusion_steps=(0, 2)))])
+def test_g8_hip_composition_matches_reference_loop(golden_dir, tmp_path, tag, kw):
+    """``sample_with_pnp_...`` of this repo on the GPU (fusion / CFG+DDIM kernels, latent cache, hook pushes, conditioning
+    assembly) against the reference's own method run on the same inputs: every UNet input batch and the final latents,
+    bit for bit"""
+    from g8_common import seeded
+    from mvoc_amd import pnp_utils
+    from mvoc_amd.schedulers import DDIMScheduler
+    g = np.load(os.path.join(golden_dir, "g8_loops.npz"))
+    Fr, h, w = int(g["frames"]), int(g["h"]), int(g["w"])
+    pipe, calls = _g8_pipe(DDIMScheduler())
+    full = DDIMScheduler()
+    full.set_timesteps(5)
+    pnp_utils.modify_diffuser_attention_forward(pipe.unet)
+    pnp_utils.register_temp_attention_pnp(pipe, full.timesteps[:5], False)
+    pnp_utils.register_spatial_attention_pnp(pipe, full.timesteps[:5], False)
+    pnp_utils.register_temp_conv_injection(pipe, full.timesteps[:2])
+    pnp_utils.register_out_conv_injection(pipe, full.timesteps[:2])
+    pnp_utils.register_resnet_injection(pipe, full.timesteps[:2])
+    dirs = {}
+    for name, key in (("bg", 20), ("obj0", 30), ("obj1", 40)):
+        d_ = tmp_path / name
+        d_.mkdir()
+        for t in full.timesteps:
+            torch.save(seeded(key * 1000 + int(t), (1, 4, Fr, h, w)), str(d_ / f"ddim_latents_{int(t)}.pt"))
+        dirs[name] = str(d_)
+    masks = [(torch.from_numpy(g[f"{tag}_mask_float"][j]).cuda(), torch.from_numpy(g[f"{tag}_mask_bool"][j]).cuda()) for j in range(2)]
+    out = pipe.sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection(
+        prompt="windsurf", main_first_image=1, main_image_list=[10 + i for i in range(Fr)], background_first_image=2,
+        background_image_list=[20 + i for i in range(Fr)], objs_first_image=[4, 5],
+        objs_image_list=[[40 + i for i in range(Fr)], [50 + i for i in range(Fr)]], height=h * 8, width=w * 8, target_fps=8,
+        num_frames=Fr, num_inference_steps=5, guidance_scale=9.0, negative_prompt="chaotic",
+        latents=torch.from_numpy(g[f"{tag}_xT"]).cuda(), output_type="latent", ddim_init_latents_t_idx=1, ddim_inv_prompt="",
+        obj_mask=["0", "1"], obj_width_height=[(w * 8, h * 8)] * 2, obj_ddim_latents_idx_offset=[0, 1],
+        bg_inv_latents_path=dirs["bg"], obj_ddim_latents_path=[dirs["obj0"], dirs["obj1"]], obj_masks_tensors=masks, **kw).frames
+    assert len(calls) == 4
+    for i, x in enumerate(calls):
+        assert torch.equal(x.cpu(), torch.from_numpy(g[f"{tag}_x"][i])), f"step {i}"
+    assert torch.equal(out.cpu(), torch.from_numpy(g[f"{tag}_out"]))
+    assert pipe.unet.up_blocks[-1].resnets[0].t == 1  # the last register_time_all push

@@ -325,6 +325,161 @@ def gen_masks(ref_utils):
     np.savez_compressed(os.path.join(OUT, "g9_boat_surf_masks.npz"), **out)
 
 
+# ---- G8: the three denoising loops, run from the reference's own pipeline methods --------------------------------
+def fake_unet(x, t, ehs, fps, ilf, il, ie):
+    """Stand-in for the UNet inside the loops: elementwise fp16 arithmetic only (bit-reproducible on any machine), a
+    different function of every input so that a wrong batch / conditioning order changes the result.  The tests carry
+    the same function (tests/test_oracle_golden.py); it is test scaffolding, not part of either code base."""
+    s = (ehs[:, 0, 0].float() * 0.01 + ie[:, 0, 0].float() * 0.02 + fps.float() * 0.001 + float(t) * 1e-4).to(x.dtype)
+    return x * 0.5 + il * 0.25 - ilf * 0.125 + s[:, None, None, None, None]
+
+
+def _seeded(key, shape, scale=1.0):
+    g = torch.Generator().manual_seed(int(key) % (2 ** 31))
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def _loop_pipe(pipeline_mod, pnp_utils, unet, scheduler, calls, Fr, h, w, D):
+    """an I2VGenXLPipeline instance without diffusers underneath: the encoders are seeded stand-ins keyed by the "image"
+    (a 1-element id tensor) / prompt string; everything between them and the scheduler is the reference's code"""
+    P = pipeline_mod.I2VGenXLPipeline
+    pipe = object.__new__(P)
+    pipe.unet, pipe.scheduler, pipe.vae_scale_factor = unet, scheduler, 8
+    pipe.device = pipe._execution_device = torch.device("cpu")
+    pipe.check_inputs = lambda *a, **k: None
+    pipe.maybe_free_model_hooks = lambda: None
+
+    class _Bar:
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def update(self): pass
+    pipe.progress_bar = lambda total=None: _Bar()
+
+    def encode_prompt(prompt, device, n, negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None, **_):
+        key = lambda s_: 7 + sum(str(s_).encode())
+        pe = prompt_embeds if prompt_embeds is not None else _seeded(key(prompt), (1, 7, D))
+        ne = negative_prompt_embeds if negative_prompt_embeds is not None else _seeded(1000 + key(negative_prompt), (1, 7, D))
+        return pe, ne
+    pipe.encode_prompt = encode_prompt
+    pipe.image_processor = types.SimpleNamespace(preprocess=lambda img: img.float())
+    pipe.feature_extractor = types.SimpleNamespace(crop_size={"width": 4, "height": 4})
+
+    class _Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1, dtype=torch.float16))
+        def forward(self, image):
+            return types.SimpleNamespace(image_embeds=_seeded(300 + int(image.reshape(-1)[0]), (1, D)))
+    pipe.image_encoder = _Enc()
+    pipe.vae = types.SimpleNamespace(
+        config=types.SimpleNamespace(scaling_factor=0.18215),
+        encode=lambda image: types.SimpleNamespace(latent_dist=types.SimpleNamespace(
+            sample=lambda: _seeded(500 + int(image.reshape(-1)[0]), (1, 4, h, w)))))
+    pipeline_mod._center_crop_wide = lambda img, size: img
+    pipeline_mod._resize_bilinear = lambda img, size: img
+
+    def unet_forward(sample, t, encoder_hidden_states=None, fps=None, image_latents=None, image_embeddings=None,
+                     image_latents_first=None, cross_attention_kwargs=None, multi_frame_guidance=False, return_dict=True, **_):
+        ilf = image_latents if image_latents_first is None else image_latents_first
+        calls.append(dict(x=sample.clone(), t=int(t), ehs=encoder_hidden_states.clone(), fps=fps.clone(), ilf=ilf.clone(),
+                          il=image_latents.clone(), ie=image_embeddings.clone(), mfg=bool(multi_frame_guidance),
+                          hook_t=getattr(unet.up_blocks[-1].resnets[0], "t", None)))
+        ie = image_embeddings if image_embeddings.dim() == 3 else image_embeddings[:, None]
+        return (fake_unet(sample, t, encoder_hidden_states, fps, ilf, image_latents, ie),)
+    unet.forward = unet_forward
+    return pipe
+
+
+def gen_loops(pnp_utils, pipeline_mod):
+    """G8: ``invert`` (a1), ``__call__`` (a3) and ``sample_with_pnp_...`` (a2) of the reference, with its own
+    ``prepare_image_latents`` / ``_encode_image`` / ``prepare_latents`` / batch assembly / fusion / CFG / permutes and the
+    oracle's scheduler restatement (diffusers' is absent); the UNet is ``fake_unet``.  Recorded: everything the UNet
+    was called with at every step, the hook state pushed by ``register_time_all`` before each call, the final latents
+    and the written ``ddim_latents_{t}.pt`` files."""
+    import tempfile
+    from oracle.sched_ref import DDIMInverseSchedulerRef
+    Fr, h, w, D = 3, 4, 4, 64
+    cfg = U.UNetConfig.small4()
+    save = {"frames": Fr, "h": h, "w": w, "dim": D}
+    img = lambda i: torch.tensor([float(i)])
+
+    def dump(tag, calls):
+        save[f"{tag}_ncalls"] = len(calls)
+        for k in ("x", "ehs", "fps", "ilf", "il", "ie"):
+            save[f"{tag}_{k}"] = np.stack([_np(c[k]) for c in calls])
+        save[f"{tag}_t"] = np.array([c["t"] for c in calls])
+        save[f"{tag}_mfg"] = np.array([c["mfg"] for c in calls])
+        save[f"{tag}_hook_t"] = np.array([-1 if c["hook_t"] is None else int(c["hook_t"]) for c in calls])
+
+    with torch.no_grad(), tempfile.TemporaryDirectory() as td:
+        # ---- a1: invert, cfg 1.0 (inverse.py's setting) and cfg 7.5 ------------------------------------------------
+        for tag, gs in (("inv_cfg1", 1.0), ("inv_cfg75", 7.5)):
+            unet = U.I2VGenXLUNet(cfg)
+            calls = []
+            pipe = _loop_pipe(pipeline_mod, pnp_utils, unet, DDIMInverseSchedulerRef(), calls, Fr, h, w, D)
+            out_dir = os.path.join(td, tag)
+            x0 = _seeded(11, (1, 4, Fr, h, w))
+            seq = pipe.invert(prompt="a boat", image=img(3), height=h * 8, width=w * 8, target_fps=8, num_frames=Fr,
+                              num_inference_steps=4, guidance_scale=gs, negative_prompt="bad", latents=x0.clone(),
+                              return_dict=False, output_dir=out_dir)
+            seq = seq[0] if isinstance(seq, (tuple, list)) else seq
+            dump(tag, calls)
+            save[f"{tag}_x0"], save[f"{tag}_out"] = _np(x0), _np(seq)
+            files = sorted(os.listdir(out_dir))
+            save[f"{tag}_files"] = np.array(files)
+            save[f"{tag}_file_latents"] = np.stack([_np(torch.load(os.path.join(out_dir, f))) for f in files])
+        # ---- a3: __call__ from a stored latent, cfg 9.0, ddim_init_latents_t_idx 1 -------------------------------------
+        unet = U.I2VGenXLUNet(cfg)
+        calls = []
+        pipe = _loop_pipe(pipeline_mod, pnp_utils, unet, DDIMSchedulerRef(), calls, Fr, h, w, D)
+        xT = _seeded(12, (1, 4, Fr, h, w))
+        res = pipe(prompt="a boat", image=img(3), height=h * 8, width=w * 8, target_fps=8, num_frames=Fr, num_inference_steps=4,
+                   guidance_scale=9.0, negative_prompt="bad", latents=xT.clone(), output_type="latent",
+                   ddim_init_latents_t_idx=1, decode_chunk_size=1)
+        dump("call", calls)
+        save["call_xT"], save["call_out"] = _np(xT), _np(res.frames)
+        # ---- a2: composition, 2 objects, all hook families registered as composite.py does -----------------------------
+        for tag, kw in (("comp", dict(random_noise_ratio=0.0, obj_random_noise_fusion=False, fusion_steps=(0, 1))),
+                        ("comp_rnf", dict(random_noise_ratio=0.3, obj_random_noise_fusion=True, fusion_steps=(0, 2)))):
+            unet = U.I2VGenXLUNet(cfg)
+            calls = []
+            sched = DDIMSchedulerRef()
+            pipe = _loop_pipe(pipeline_mod, pnp_utils, unet, sched, calls, Fr, h, w, D)
+            full = DDIMSchedulerRef()
+            full.set_timesteps(5)
+            holder = _Pipe(unet)
+            pnp_utils.modify_diffuser_attention_forward(unet)
+            pnp_utils.register_temp_attention_pnp(holder, full.timesteps[:5], False)
+            pnp_utils.register_spatial_attention_pnp(holder, full.timesteps[:5], False)
+            pnp_utils.register_temp_conv_injection(holder, full.timesteps[:2])
+            pnp_utils.register_out_conv_injection(holder, full.timesteps[:2])
+            pnp_utils.register_resnet_injection(holder, full.timesteps[:2])
+            masks = _masks(Fr, h, w, seed=8)
+            pipeline_mod.mask_preprocess = lambda om, device, dtype, b, c, f, downscale=8: masks[int(om)]
+            dirs = {}
+            for name, key in (("bg", 20), ("obj0", 30), ("obj1", 40)):
+                d_ = os.path.join(td, f"{tag}_{name}")
+                os.makedirs(d_)
+                for t in full.timesteps:
+                    torch.save(_seeded(key * 1000 + int(t), (1, 4, Fr, h, w)), os.path.join(d_, f"ddim_latents_{int(t)}.pt"))
+                dirs[name] = d_
+            xT = _seeded(13, (1, 4, Fr, h, w))
+            res = pipe.sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection(
+                prompt="windsurf", main_first_image=img(1), main_image_list=[img(10 + i) for i in range(Fr)],
+                background_first_image=img(2), background_image_list=[img(20 + i) for i in range(Fr)],
+                objs_first_image=[img(4), img(5)], objs_image_list=[[img(40 + i) for i in range(Fr)], [img(50 + i) for i in range(Fr)]],
+                height=h * 8, width=w * 8, target_fps=8, num_frames=Fr, num_inference_steps=5, guidance_scale=9.0,
+                negative_prompt="chaotic", latents=xT.clone(), output_type="latent", ddim_init_latents_t_idx=1,
+                ddim_inv_prompt="", obj_mask=["0", "1"], obj_width_height=[(w * 8, h * 8)] * 2,
+                obj_ddim_latents_idx_offset=[0, 1], bg_inv_latents_path=dirs["bg"],
+                obj_ddim_latents_path=[dirs["obj0"], dirs["obj1"]], **kw)
+            dump(tag, calls)
+            save[f"{tag}_xT"], save[f"{tag}_out"] = _np(xT), _np(res.frames)
+            save[f"{tag}_mask_float"] = np.stack([_np(m[0]) for m in masks])
+            save[f"{tag}_mask_bool"] = np.stack([_np(m[1]) for m in masks])
+    np.savez_compressed(os.path.join(OUT, "g8_loops.npz"), **save)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -338,6 +493,7 @@ def main():
     gen_transformer_forwards(pnp_utils)
     gen_unet_ext(pnp_utils, pipeline_i2vgen_xl)
     gen_masks(ref_utils)
+    gen_loops(pnp_utils, pipeline_i2vgen_xl)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
