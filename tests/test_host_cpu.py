@@ -1,6 +1,7 @@
 """CPU-only checks: the C-ABI library loads and exports every symbol the header declares, the host logic
 (parameter table, schedulers, hook registration) agrees with the oracle.  No kernel is launched here."""
 import os
+import sys
 import re
 import types
 
@@ -135,3 +136,70 @@ def test_hook_registration_sites_and_state():
     # attn2 / down / mid processors get t and mask pushed but never inject (no schedule registered there)
     p = eng.mid_block.attentions[0].transformer_blocks[0].attn2.processor
     assert p.t == 1 and p.mask is masks and not p.injecting()
+
+
+# ---- G10 (a15): composite.init_pnp against the reference's, for the 7 demo entries ----------------------------------
+def _hooked_state(eng):
+    """walk the engine's attribute tree by the reference's module paths"""
+    out = {}
+
+    def rec(path, holder):
+        # every hookable node of the engine carries the attribute (None until registered); the reference sets it only on
+        # the modules it registers
+        if getattr(holder, "injection_schedule", None) is not None:
+            sch = holder.injection_schedule
+            out[path] = {"schedule": [int(v) for v in sch],
+                         "inject_background": bool(getattr(holder, "inject_background", False))}
+
+    blocks = [(f"down_blocks.{i}", b) for i, b in enumerate(eng.down_blocks)] + [("mid_block", eng.mid_block)] + \
+             [(f"up_blocks.{i}", b) for i, b in enumerate(eng.up_blocks)]
+    for bp, b in blocks:
+        for kind in ("resnets", "temp_convs"):
+            for j, m in enumerate(getattr(b, kind)):
+                rec(f"{bp}.{kind}.{j}", m)
+        for kind in ("attentions", "temp_attentions"):
+            for j, m in enumerate(getattr(b, kind)):
+                for a in ("attn1", "attn2"):
+                    attn = getattr(m.transformer_blocks[0], a)
+                    rec(f"{bp}.{kind}.{j}.transformer_blocks.0.{a}", attn)
+                    rec(f"{bp}.{kind}.{j}.transformer_blocks.0.{a}.processor", attn.processor)
+    rec("conv_out", eng.conv_out)
+    rec("conv_in", eng.conv_in)
+    for a in ("attn1", "attn2"):
+        attn = getattr(eng.transformer_in.transformer_blocks[0], a)
+        rec(f"transformer_in.transformer_blocks.0.{a}.processor", attn.processor)
+    return out
+
+
+def test_g10_init_pnp_matches_reference():
+    """the harness's ``init_pnp`` (i2vgen-xl/composite.py) on this repo's engine + scheduler puts the same injection
+    schedules and ``inject_background`` flags on the same module paths as the REFERENCE's ``init_pnp`` did on the oracle
+    tree (tests/golden/g10_init_pnp.json, recorded by tools/gen_golden.py for the 7 entries of group_composite)"""
+    import importlib
+    import json
+    import types
+    from mvoc_amd.schedulers import DDIMScheduler
+    from mvoc_amd.unet import I2VGenXLUNet
+    from mvoc_amd.unet_spec import UNetConfig
+    sys.path.insert(0, os.path.join(REPO, "i2vgen-xl"))
+    try:
+        composite = importlib.import_module("composite")
+    finally:
+        sys.path.pop(0)
+    assert composite.__file__.startswith(REPO)
+    cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
+                     attention_head_dim=64, transformer_in_heads=2, context_pool=8)
+    golden = json.load(open(os.path.join(REPO, "tests", "golden", "g10_init_pnp.json")))
+    assert [e["video_name"] for e in golden] == ["boat_surf", "crane_seal", "duck_crane", "monkey_swan", "rider_deer_road",
+                                                 "table_robot_cat", "seal_bird"]
+    for e in golden:
+        eng = I2VGenXLUNet(cfg, device="cpu").init_random(1)
+        sched = DDIMScheduler()
+        sched.set_timesteps(e["config"]["n_steps"])
+        composite.init_pnp(types.SimpleNamespace(unet=eng), sched, types.SimpleNamespace(**e["config"]))
+        got = _hooked_state(eng)
+        assert got == e["hooked"], (e["video_name"], sorted(set(got) ^ set(e["hooked"]))[:6])
+    # the known answers of SURVEY 8a15 for boat_surf: conv = first 5 timesteps, both attention kinds = all 50
+    bs = golden[0]["hooked"]
+    assert bs["conv_out"]["schedule"] == [981, 961, 941, 921, 901] and len(bs) == 23
+    assert all(len(v["schedule"]) == 50 for k, v in bs.items() if k.endswith(".processor"))

@@ -480,6 +480,38 @@ def gen_loops(pnp_utils, pipeline_mod):
     np.savez_compressed(os.path.join(OUT, "g8_loops.npz"), **save)
 
 
+# ---- G10: composite.init_pnp (a15): which modules get which injection schedule, for the 7 demo entries ---------------
+def hooked_state(unet):
+    """{module path: [schedule..] (+ inject_background)} for everything the registration functions touched"""
+    out = {}
+    for name, m in unet.named_modules():
+        for holder, suffix in ((m, ""), (getattr(m, "processor", None), ".processor")):
+            if holder is not None and hasattr(holder, "injection_schedule"):
+                sch = holder.injection_schedule
+                out[name + suffix] = {"schedule": [int(v) for v in sch] if sch is not None else None,
+                                      "inject_background": bool(getattr(holder, "inject_background", False))}
+    return out
+
+
+def gen_init_pnp():
+    import json
+    import yaml
+    import composite as ref_composite  # the reference's harness
+    assert ref_composite.__file__.startswith(REF)
+    tmpl = yaml.safe_load(open(os.path.join(REF, "i2vgen-xl", "configs", "group_composite", "template.yaml")))
+    entries = json.load(open(os.path.join(REF, "i2vgen-xl", "configs", "group_composite", "group_config.json")))
+    keys = ("n_steps", "pnp_f_t", "pnp_spatial_attn_t", "pnp_temp_attn_t", "pnp_cross_attn_t", "inject_background")
+    out = []
+    for e in entries:
+        cfg = types.SimpleNamespace(**{k: e.get(k, tmpl[k]) for k in keys})
+        unet = U.I2VGenXLUNet(U.UNetConfig.small4())
+        sched = DDIMSchedulerRef()
+        sched.set_timesteps(cfg.n_steps)
+        ref_composite.init_pnp(_Pipe(unet), sched, cfg)
+        out.append({"video_name": e["video_name"], "config": vars(cfg), "hooked": hooked_state(unet)})
+    json.dump(out, open(os.path.join(OUT, "g10_init_pnp.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
@@ -494,6 +526,7 @@ def main():
     gen_unet_ext(pnp_utils, pipeline_i2vgen_xl)
     gen_masks(ref_utils)
     gen_loops(pnp_utils, pipeline_i2vgen_xl)
+    gen_init_pnp()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
