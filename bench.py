@@ -344,12 +344,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    local_rank %= max(torch.cuda.device_count(), 1)  # (tests launch two ranks on a one-GPU box)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)  # RCCL; the metric workload uses it for barrier + max-reduce only
+        backend = os.environ.get("MVOC_BENCH_BACKEND", "nccl")  # RCCL; "gloo" only for the one-GPU test of this code path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # the metric workload uses it for barrier + max-reduce only
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "longclip":
         return longclip(args, rank, world, device, dist)

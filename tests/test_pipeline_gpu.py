@@ -344,3 +344,21 @@ def test_g8_hip_composition_matches_reference_loop(golden_dir, tmp_path, tag, kw
         assert torch.equal(x.cpu(), torch.from_numpy(g[f"{tag}_x"][i])), f"step {i}"
     assert torch.equal(out.cpu(), torch.from_numpy(g[f"{tag}_out"]))
     assert pipe.unet.up_blocks[-1].resnets[0].t == 1  # the last register_time_all push
+
+
+def test_bench_two_rank_protocol(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, env rendezvous on 127.0.0.1), on this one-GPU
+    box with the gloo backend standing in for RCCL: both ranks build their shard, barrier, time, MAX-reduce, rank 0 prints
+    ONE JSON line whose value is the whole-job aggregate (2 shards) with "scaling": "weak" """
+    import subprocess
+    env = dict(os.environ, MVOC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--frames", "4", "--latent", "32", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 4 and j["unit"] == "steps/s"
+    assert abs(j["value"] - 2 * 4 / (j["ms_per_step"] * 4 / 1e3)) / j["value"] < 1e-3  # aggregate = world * steps / time
