@@ -1183,16 +1183,6 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 15:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
       return launch_glds<2, 4, 2, 2>(a, s);  // 128 x 256, 8 waves
-    // software-pipelined LDS fragment reads
-    case 31:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 2, 2, 2, 2, 1>(a, s);
-    case 32:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 32 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 2, 1>(a, s);
-    case 33:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<1, 4, 2, 1, 2, 1>(a, s);
     // K step 32: half the LDS per block -> more resident blocks per CU
     case 61:
       MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 61 needs k, cin, c1 %% 64 == 0 and row statistics");
@@ -1220,38 +1210,6 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 67:
       MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 67 needs k, cin, c1 %% 64 == 0 and row statistics");
       return launch_glds<2, 4, 4, 2, 2, 0, 32>(a, s);  // 256 x 256
-    // three-stage rings at K step 32 (two K steps of loads in flight at the LDS footprint of a two-stage K-step-64 ring)
-    case 71:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 71 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<2, 2, 2, 2, 3, 0, 32>(a, s);  // 128 x 128
-    case 77:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 77 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<2, 4, 4, 2, 3, 0, 32>(a, s);  // 256 x 256, 8 waves
-    case 52:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 52 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 2, 2>(a, s);  // 160 x 128 with s_setprio around the MFMA clusters
-    case 25:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 4, 2, 2, 3, 0>(a, s);  // 128 x 256, 8 waves, 3-stage ring
-    case 45:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 4, 2, 2, 3, 1>(a, s);
-    case 41:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 2, 2, 2, 3, 1>(a, s);
-    case 42:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 42 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 3, 1>(a, s);
-    // 3-stage ring, counted vmcnt (two K steps in flight)
-    case 21:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 2, 2, 2, 3>(a, s);
-    case 22:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 22 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 4, 5, 1, 3>(a, s);
-    case 23:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<1, 4, 2, 1, 3>(a, s);
     default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
   }
 }

@@ -35,13 +35,13 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 21, 22, 23, 61, 62, 63, 64, 65, 66, 67])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
     maps (asymmetric data) are checked bit for bit"""
     g = torch.Generator().manual_seed(tile * 1000 + m)
-    n, k = 320, (320 if tile > 10 else 96)  # 5 K steps of 64: exercises the 3-stage ring's prologue, steady state and drain
+    n, k = 320, (320 if tile > 10 else 96)  # 5 K steps of 64 (10 of 32): ring prologue, steady state and drain
     x = torch.randint(-3, 4, (m, k), generator=g).float()
     w = torch.randint(-3, 4, (n, k), generator=g).float()
     b = torch.randint(-8, 9, (n,), generator=g).float()
@@ -164,7 +164,7 @@ def _from_rows(r, n, h, w):
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 21, 23, 61, 63])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 8, 8, 1), (32, 96, 7, 9, 1), (64, 128, 9, 6, 2), (8, 64, 8, 8, 1)])
 def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     if tile and cin % 64:
@@ -182,7 +182,7 @@ def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 21, 23, 61, 63])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63])
 def test_conv3x3_concat_glds(ops, tile):
     """two-source gather (decoder skip concat) with both channel counts multiples of 64"""
     from mvoc_amd.unet import pack_conv3x3
@@ -230,7 +230,7 @@ def test_conv3x3_upsample(ops, size, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 21, 23, 61, 63])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63])
 @pytest.mark.parametrize("frames", [1, 3, 16])
 def test_tconv3(ops, frames, tile):
     from mvoc_amd.unet import pack_tconv

@@ -72,11 +72,11 @@ for key, (d, cnt) in rec.items():
         d.tile = tile
         if tile == 66 and (d.act == 1 or d.n % 320):
             continue
-        if tile in (67, 77) and d.n % 256:
+        if tile == 67 and d.n % 256:
             continue
-        if tile in (2, 12, 14, 22, 32, 42, 52, 62, 64) and (d.act == 1 or d.n % 160):
+        if tile in (2, 12, 14, 62, 64) and (d.act == 1 or d.n % 160):
             continue
-        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 31, 33, 41, 25, 45, 61, 63, 65, 67, 71, 77):
+        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 61, 63, 65, 67):
             continue
         try:
             for _ in range(2):
