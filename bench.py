@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--workload", default="boat_surf", choices=["boat_surf", "longclip"],
                     help="boat_surf = the metric (BASELINE configs[1], per-object shards across GPUs, weak scaling); longclip = "
                          "BASELINE configs[3]: ONE 32-frame 768x768 clip, frame axis sharded over the GPUs (strong scaling)")
+    ap.add_argument("--batch-inversions", action="store_true",
+                    help="diagnostic: the 3 source inversions of the job share one UNet call per step (batch 3, "
+                         "I2VGenXLPipeline.invert_many) instead of three calls at batch 1; --steps must be a multiple of 4")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="longclip: frame<->pixel exchange form")
     return ap.parse_args()
 
@@ -76,6 +79,8 @@ class Job:
         self.inv_state = pipe._make_stock_step("bench-inv", self.inv_latents, self.inv_cond, 1.0)
         self.inv_table, self.inv_index = self.inv_sched.coef_table(dev, 1.0)
         self.inv_i = 0
+        self.batch_inversions = False
+        self.inv3_state = None
         # ---- composition stream (composite.py on the boat_surf entry of group_composite/group_config.json) -----
         self.sched = DDIMScheduler()
         self.sched.set_timesteps(50)
@@ -119,7 +124,21 @@ class Job:
         self._hooks_live = False
         self.mix = "job"
 
+    def enable_batched_inversions(self):
+        """the job's three source inversions (bg, obj1, obj2) as ONE loop at UNet batch 3"""
+        pipe = self.pipe
+        saved, pipe._guidance_scale = pipe._guidance_scale, 1.0  # inverse.py's cfg: no CFG duplication of the conditioning
+        conds = [pipe._stock_conditioning("", "", f"source-{j}", self.F, self.h * 8, self.h * 8, 8, None, None, None, None)
+                 for j in range(3)]
+        pipe._guidance_scale = saved
+        cond = {k: torch.cat([c[k] for c in conds]).contiguous() for k in conds[0]}
+        lat = torch.cat([self.inv_latents, self.inv_latents.flip(2), self.inv_latents.flip(3)])
+        self.inv3_state = pipe._make_stock_step("bench-inv3", lat, cond, 1.0)
+        self.batch_inversions = True
+
     def inversion_step(self):
+        if self.batch_inversions:
+            return self.batched_inversion_step()
         if self._hooks_live:  # the two stages share one engine here: clear the composition's hook state
             from mvoc_amd import pnp_utils
             pnp_utils.register_time_all(self.pipe, None, None)
@@ -131,6 +150,19 @@ class Job:
         st["coef"].copy_(self.inv_table[self.inv_index[t]])
         st["run"]()
         return st["latents"].clone()  # the per-step snapshot invert() appends / hands to the latent cache
+
+    def batched_inversion_step(self):
+        if self._hooks_live:
+            from mvoc_amd import pnp_utils
+            pnp_utils.register_time_all(self.pipe, None, None)
+            self._hooks_live = False
+        t = int(self.inv_sched.timesteps[self.inv_i % 50])
+        self.inv_i += 1
+        st = self.inv3_state
+        st["t"].fill_(float(t))
+        st["coef"].copy_(self.inv_table[self.inv_index[t]])
+        st["run"]()
+        return st["latents"].clone()
 
     def composition_step(self):
         i = self.comp_i % 50
@@ -147,8 +179,10 @@ class Job:
     def step(self, k):
         if self.is_comp(k):
             self.composition_step()
-        else:
+        elif not self.batch_inversions:
             self.inversion_step()
+        elif k % 4 == 0:  # steps k, k+1, k+2 of the mix are the three sources' inversion steps: one batched call
+            self.batched_inversion_step()
 
 
 def roofline_leg(job, steps):
@@ -360,6 +394,11 @@ def main():
         return longclip(args, rank, world, device, dist)
     job = Job(device, args.frames, args.latent, not args.no_graphs)
     job.mix = args.mix
+    if args.batch_inversions:
+        if args.steps % 4 or args.mix != "job":
+            raise SystemExit("--batch-inversions needs --mix job and --steps % 4 == 0 (one batched call = 3 inversion steps)")
+        job.enable_batched_inversions()
+        args.no_roofline = True  # the roofline leg brackets the metric's own (unbatched) steps
     # prime every graph variant the timed region will replay, then W untimed warm-up steps
     for k in range(4):
         job.step(k)
@@ -410,7 +449,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {
-                "workload": f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "
+                "workload": ("[--batch-inversions: the 3 inversion steps of each mix period run as ONE UNet call at batch 3] " if args.batch_inversions else "") +
+                            f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "
                             f"(UNet batch 5 = bg+2 objects+uncond+cond, cfg 9.0, all 5 injection families), "
                             f"{args.frames} frames x {args.latent * 8}x{args.latent * 8}, 50-step DDIM schedules, fp16",
                 "frames": args.frames, "height": args.latent * 8, "width": args.latent * 8,

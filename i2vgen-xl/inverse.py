@@ -55,13 +55,49 @@ def build_pipeline(device, synthetic):
     return I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=torch.float16, variant="fp16", device=device)
 
 
-def main(template_config, configs_list, device, synthetic=False, frame_shard=None):
+def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch):
+    """--batch_entries N: invert up to N pending clips of identical shape / step count in one batched loop
+    (``I2VGenXLPipeline.invert_many``) before the per-entry pass below, which then finds their latents on disk"""
+    pending = []
+    for entry in configs_list:
+        if not entry["active"]:
+            continue
+        config = OmegaConf.merge(template_config, OmegaConf.create(entry))
+        inv = config.inverse_config
+        if (os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False)) or inv.cfg > 1:
+            continue
+        config.video_frames_path = os.path.join(config.video_dir, config.video_name)
+        _, frame_list = load_video_frames(config.video_frames_path, config.n_frames, config.image_size)
+        first_frame = frame_list[0]
+        if inv.inverse_static_video:
+            frame_list = [frame_list[0]] * config.n_frames
+        if inv.null_image_inversion:
+            first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
+        key = (tuple(inv.image_size), inv.n_frames, inv.n_steps, inv.target_fps, str(inv.negative_prompt))
+        pending.append((key, inv, first_frame, frame_list))
+    pipe.scheduler = inverse_scheduler
+    while pending:
+        key = pending[0][0]
+        group = [p for p in pending if p[0] == key][:batch]
+        pending = [p for p in pending if all(p is not g_ for g_ in group)]
+        inv0 = group[0][1]
+        lat = [pipe.encode_vae_video(fl, device=pipe._execution_device, height=inv0.image_size[1], width=inv0.image_size[0])
+               for _, _, _, fl in group]
+        logger.info(f"batched inversion of {len(group)} clips: {[g_[1].output_dir for g_ in group]}")
+        pipe.invert_many([g_[1].prompt for g_ in group], [g_[2] for g_ in group], lat, [g_[1].output_dir for g_ in group],
+                         height=inv0.image_size[1], width=inv0.image_size[0], target_fps=inv0.target_fps, num_frames=inv0.n_frames,
+                         num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt)
+
+
+def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1):
     pipe = build_pipeline(device, synthetic)
     if frame_shard is not None:
         pipe.enable_frame_shard(frame_shard)
     g = torch.Generator().manual_seed(template_config.seed)
     inverse_scheduler = DDIMInverseScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
     ddim_scheduler = DDIMScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
+    if batch_entries > 1:
+        batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch_entries)
     for entry in configs_list:
         if not entry["active"]:
             logger.info(f"Skipping config_entry: {entry}")
@@ -105,6 +141,8 @@ if __name__ == "__main__":
     ap.add_argument("--frame_shard", action="store_true",
                     help="under torchrun: every rank works on the SAME entries, each clip's frame axis sharded over the ranks "
                          "(RCCL; for clips too long for one GPU's latency budget) instead of one entry per rank")
+    ap.add_argument("--batch_entries", type=int, default=1,
+                    help="invert up to N clips of identical shape in one batched UNet loop (one GPU, cfg 1.0 inversions)")
     args = ap.parse_args()
     template_config = OmegaConf.load(args.template_config)
     logging.basicConfig(level=logging.DEBUG if template_config.debug else logging.INFO,
@@ -124,4 +162,4 @@ if __name__ == "__main__":
         dist.barrier()
         dist.destroy_process_group()
     else:
-        main(template_config, my_entries(configs_list, args.shard), device, args.synthetic)
+        main(template_config, my_entries(configs_list, args.shard), device, args.synthetic, batch_entries=args.batch_entries)

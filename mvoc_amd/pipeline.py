@@ -209,7 +209,7 @@ class I2VGenXLPipeline:
               "coef": torch.zeros(5, dtype=torch.float32, device=self.device)}
         do_cfg = guidance_scale > 1
         # loop-invariant conditioning (context tokens, cross-attention K/V, image-latent stem): once per loop, not per step
-        shape = (2 if do_cfg else 1,) + tuple(latents.shape[1:])
+        shape = (latents.shape[0] * (2 if do_cfg else 1),) + tuple(latents.shape[1:])
         prepared = self.unet.prepare_conditioning(shape, cond["fps"], cond["image_latents"], cond["image_latents"],
                                                   cond["image_embeddings"], cond["encoder_hidden_states"], False)
 
@@ -271,6 +271,35 @@ class I2VGenXLPipeline:
         if not return_dict:
             return inverted
         return PipelineOutput(inverted_latents=inverted)
+
+    @torch.no_grad()
+    def invert_many(self, prompts, images, latents, output_dirs, height=704, width=1280, target_fps=16, num_frames=16,
+                    num_inference_steps=50, guidance_scale=1.0, negative_prompt=None):
+        """DDIM-invert several source clips of the same shape in ONE batched loop: the per-object inversions of a
+        composition job (background + N objects) are independent (``inverse.py:136-190`` runs them one after another),
+        so on one GPU they can share every weight read -- UNet batch n instead of n passes at batch 1.  Same files, same
+        return value per clip as ``invert``; guidance 1.0 only (the setting of ``group_inversion/template.yaml``)."""
+        if guidance_scale > 1:
+            raise NotImplementedError("invert_many batches the cfg = 1.0 inversions of inverse.py; use invert() for CFG")
+        n = len(prompts)
+        if not (len(images) == len(latents) == len(output_dirs) == n and n > 0):
+            raise ValueError("invert_many: prompts, images, latents and output_dirs must have the same length")
+        self._guidance_scale = guidance_scale
+        conds = [self._stock_conditioning(p, negative_prompt, im, num_frames, height, width, target_fps, None, None, None, None)
+                 for p, im in zip(prompts, images)]
+        cond = {k: torch.cat([c[k] for c in conds]).contiguous() for k in conds[0]}
+        lat = torch.cat([self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, None, l) for l in latents])
+        seqs = [[] for _ in range(n)]
+
+        def on_step(i, t, cur):
+            for j in range(n):
+                snap = cur[j:j + 1].clone()
+                seqs[j].append(snap)
+                self.latent_cache.put(output_dirs[j], t, snap)
+
+        self._run_stock_loop(lat, cond, num_inference_steps, guidance_scale, on_step=on_step)
+        self.latent_cache.flush()
+        return [torch.stack(list(reversed(s_)), 1) for s_ in seqs]
 
     @torch.no_grad()
     def __call__(self, prompt=None, image=None, height=704, width=1280, target_fps=16, num_frames=16,

@@ -214,6 +214,17 @@ def test_dropin_drivers_end_to_end(tmp_path):
     for n in ("clipA", "clipB"):
         files = sorted(os.listdir(data / "inversions" / "i2vgen-xl" / n / "ddim_latents"))
         assert files == sorted(f"ddim_latents_{t}.pt" for t in (1, 201, 401, 601, 801))
+    # --batch_entries 2: both clips inverted in one batched loop into a second tree; same latents (batch-size noise only)
+    tmpl2 = OmegaConf.load(os.path.join(REPO, "tests", "data", "inversion_template.yaml"))
+    tmpl2.data_dir = str(data)
+    tmpl2.inv_dir = "inversions_batched"
+    entries2 = [dict(e, force_recompute_latents=False, recon_config={"enable_recon": False}) if e.get("active") else e for e in entries]
+    inverse.main(tmpl2, entries2, torch.device("cuda:0"), synthetic=True, batch_entries=2)
+    for n in ("clipA", "clipB"):
+        for t in (1, 201, 401, 601, 801):
+            a = torch.load(data / "inversions" / "i2vgen-xl" / n / "ddim_latents" / f"ddim_latents_{t}.pt")
+            b = torch.load(data / "inversions_batched" / "i2vgen-xl" / n / "ddim_latents" / f"ddim_latents_{t}.pt")
+            assert a.shape == b.shape and (a.float() - b.float()).abs().max() < 3e-2
     assert (data / "inversions" / "i2vgen-xl" / "clipA" / "ddim_reconstruction_latents.pt").exists()
     ct = OmegaConf.load(os.path.join(REPO, "tests", "data", "composite_template.yaml"))
     ct.data_dir = str(data)
@@ -231,6 +242,49 @@ def test_dropin_drivers_end_to_end(tmp_path):
     assert sub == ["ddim_init_latents_t_idx_0_nsteps_5_cfg_9.0_pnpf0.2_pnps1.0_pnpt1.0_ratio0.0noise_fusion_step0-1"]
     lat = torch.load(out_root / sub[0] / "video_latents.pt")
     assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
+
+
+def test_invert_many_matches_separate_inversions(tmp_path):
+    """batched inversion of three clips (UNet batch 3) == three inversions at batch 1: same files, same return values up to
+    the GEMM-tile / accumulation-order noise of a different batch size (5 steps: <= 3e-2 like the loop-vs-oracle tests);
+    with the elementwise stand-in UNet of the G8 tests the two are bit-identical"""
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    _, eng = _pair()
+    g = torch.Generator().manual_seed(5)
+    f, h, w = 3, 8, 8
+    x0 = [torch.randn(1, 4, f, h, w, generator=g).half().cuda() for _ in range(3)]
+    prompts, images = ["a", "", "c d"], ["img0", "img1", "img2"]
+
+    class Cond:
+        vae_scale_factor, cross_attention_dim = 8, 64
+
+        def _t(self, key, shape):
+            return torch.randn(shape, generator=torch.Generator().manual_seed(sum(str(key).encode()))).half().cuda()
+
+        def encode_prompt(self, prompt, negative_prompt=None):
+            return self._t("p" + str(prompt), (1, 7, 64)), self._t("n" + str(negative_prompt), (1, 7, 64))
+
+        def encode_image(self, image):
+            return self._t("i" + str(image), (1, 1, 64))
+
+        def image_latents(self, image, num_frames, height, width):
+            return self._t("l" + str(image), (1, 4, num_frames, height // 8, width // 8))
+
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), conditioner=Cond(), use_graphs=True)
+    kw = dict(height=h * 8, width=w * 8, target_fps=8, num_frames=f, num_inference_steps=5, guidance_scale=1.0)
+    single = [pipe.invert(prompt=p, image=im, latents=x, return_dict=False, output_dir=str(tmp_path / f"s{j}"), **kw)
+              for j, (p, im, x) in enumerate(zip(prompts, images, x0))]
+    many = pipe.invert_many(prompts, images, x0, [str(tmp_path / f"m{j}") for j in range(3)], **kw)
+    for j in range(3):
+        assert many[j].shape == single[j].shape == (1, 5, 4, f, h, w)
+        assert (many[j].float() - single[j].float()).abs().max() < 3e-2
+        for t in (1, 201, 401, 601, 801):
+            a = torch.load(tmp_path / f"m{j}" / f"ddim_latents_{t}.pt")
+            assert a.dtype == torch.float16 and tuple(a.shape) == (1, 4, f, h, w)
+            assert (a.float() - torch.load(tmp_path / f"s{j}" / f"ddim_latents_{t}.pt").float()).abs().max() < 3e-2
+    with pytest.raises(NotImplementedError):
+        pipe.invert_many(prompts, images, x0, ["a", "b", "c"], **dict(kw, guidance_scale=7.5))
 
 
 # ---- G8: the HIP pipeline's loops against the REFERENCE's own loops (tests/golden/g8_loops.npz) -----------------------
