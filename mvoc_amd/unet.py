@@ -385,6 +385,10 @@ class I2VGenXLUNet:
     def __init__(self, config=None, device="cuda:0"):
         self.config = UNetConfig.from_any(config) if config is not None else UNetConfig()
         self.device = torch.device(device)
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            # one process per GPU: the library launches on the CURRENT device's current stream, so the engine's device
+            # becomes the process's current device (launch.pick_device hands rank i its own GPU)
+            torch.cuda.set_device(self.device)
         self.dtype = H16
         self.num_upsamplers = len(self.config.block_out_channels) - 1
         self._mask_cache = (None, None)
