@@ -77,6 +77,10 @@ typedef struct mvoc_gemm_desc {
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
+/* scratch for the deterministic split-K form of a launch: the most the auto policy uses is 8 slices of m*n fp32
+ * partials; 0 when the policy would never split this shape (m > 8192 or k < 2048).  Passing no workspace is always valid:
+ * the launch then runs unsplit. */
+size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention, head_dim 64, softmax(Q K^T / 8) V, no mask (F.scaled_dot_product_attention at

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mvoc_version": (i32, []),
     "mvoc_last_error": (C.c_char_p, []),
     "mvoc_gemm_f16": (i32, [C.POINTER(GemmDesc), vp]),
+    "mvoc_gemm_workspace_bytes": (sz, [i64, i64, i64]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -1008,6 +1008,11 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
 
 }  // namespace
 
+extern "C" size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  if (m <= 0 || n <= 0 || k < 2048 || m > 8192) return 0;
+  return (size_t)8 * (size_t)m * (size_t)n * sizeof(float);
+}
+
 extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   MVOC_REQUIRE(d && d->a && d->w && d->out, -1, "gemm: null operand");
   MVOC_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, -1, "gemm: empty problem m=%ld n=%ld k=%ld", (long)d->m, (long)d->n,

@@ -43,9 +43,11 @@ def _rowmajor(t, name):
 
 def _gemm(d: GemmDesc, dev=None):
     # problems with few output tiles and a deep K get a scratch for deterministic split-K (see gemm.hip)
-    if dev is not None and d.m <= 8192 and d.k >= 2048 and d.act != ACT_GEGLU and d.split_k != 1:
-        ws = torch.empty(8 * d.m * d.n, dtype=torch.float32, device=dev)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if dev is not None and d.act != ACT_GEGLU and d.split_k != 1:
+        nbytes = lib.mvoc_gemm_workspace_bytes(d.m, d.n, d.k)
+        if nbytes:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     check(lib.mvoc_gemm_f16(C.byref(d), _stream()), "gemm")
 
 
