@@ -6,11 +6,12 @@
 //   computed).  Scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_f16 with K as the row operand),
 //   so each lane holds the scores of ONE query (col = lane&31) -> row max / row sum are in-lane plus one
 //   cross-half shuffle, and the fp16-packed P^T accumulator registers are directly the column operand of
-//   O^T = V^T P^T.  V is written to LDS transposed ([d][key]) with its keys permuted into exactly the k order
-//   the accumulator layout imposes (key = 32t + 16s + 8(j>>2) + 4h + (j&3) for element j of lane-half h), so the
-//   V^T fragment is one ds_read_b128.  LDS pitches/swizzles were chosen by exhaustive bank-conflict enumeration
-//   (K: pitch 144 B conflict-free reads; V^T: pitch 160 B + 16-byte-group XOR (d>>3): conflict-free b16 writes,
-//   2-way b128 reads).
+//   O^T = V^T P^T.  V is staged ROW-major ([key][d], one ds_write_b128 per 16 bytes loaded) and its V^T fragments come
+//   from gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group fetches 4 keys x 16 d and each lane receives
+//   one d column): the accumulator layout's k order is two runs of 4 consecutive keys (32t + 16s + 4h + {0..3}, + 8), so
+//   a fragment is two such reads.  (Writing V transposed with 2-byte stores cost 16 ds_write_b16 per lane and tile:
+//   +4 % on the 4096-token self-attention, same box.)  K: pitch 144 B, conflict-free b128 reads; V: pitch 192 B, the 4
+//   rows of a transposed read fall into 4 disjoint 64-byte bank windows.
 //
 // tattn_kernel  -- temporal self-attention: one wave per (sample, pixel, head); the sequence is the frame axis
 //   (<= 32 frames), rows are strided by H*W*C in the canonical layout so no [B*HW, F, C] copy is ever made.
@@ -19,8 +20,9 @@
 
 namespace {
 
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int KPITCH = 144;
-constexpr int VPITCH = 160;
+constexpr int VPITCH = 192;  // flash kernel: row-major V rows of 128 B + 64 B pad (4 consecutive rows hit 4 disjoint 64-byte bank windows)
 
 struct AttnArgs {
   const half_t *q, *k, *v;
@@ -84,12 +86,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
       const int c = tid + i * 256;
       const int key = c >> 3, dc = c & 7;
       *reinterpret_cast<half8_t*>(Ks + key * KPITCH + dc * 16) = kreg[i];
-      const int g = vt_slot_group(key), j = vt_slot_elem(key);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int d = dc * 8 + e;
-        *reinterpret_cast<half_t*>(Vs + d * VPITCH + ((g ^ ((d >> 3) & 7)) * 16) + j * 2) = vreg[i][e];
-      }
+      *reinterpret_cast<half8_t*>(Vs + key * VPITCH + dc * 16) = vreg[i];  // row-major; transposed on the read (below)
     }
     __syncthreads();
     if (kt + 1 < ntiles) gload(kt + 1);
@@ -150,11 +147,21 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
         half8_t pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (half_t)st[t][8 * s + j];
-        const int g = (t * 2 + s) * 2 + h;
+        // V^T fragment by the hardware transpose read: each 16-lane group fetches a block of 4 keys x 16 d of the
+        // row-major image (lane 4q+p supplies row q, columns 4p..4p+3) and lane i receives column i of the 4 rows.  The
+        // accumulator's k order is two runs of 4 consecutive keys (32t + 16s + 4h + {0..3} and + 8): two reads.
+        const int krow = 32 * t + 16 * s + 4 * h + ((lane & 15) >> 2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const int d = 32 * dt + r;
-          const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + d * VPITCH + ((g ^ ((d >> 3) & 7)) * 16));
+          const char* va = Vs + krow * VPITCH + (32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+          const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
+          const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 8 * VPITCH));
+          half8_t vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[e] = (half_t)lo[e];
+            vf[4 + e] = (half_t)hi[e];
+          }
           ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
         }
       }
