@@ -416,3 +416,31 @@ def test_bench_two_rank_protocol(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 4 and j["unit"] == "steps/s"
     assert abs(j["value"] - 2 * 4 / (j["ms_per_step"] * 4 / 1e3)) / j["value"] < 1e-3  # aggregate = world * steps / time
+
+
+def test_fifty_step_inversion_drift_vs_oracle():
+    """SURVEY 8d tolerance proposal: latents after a full 50-step schedule within rel-L2 2e-2 of the fp32 oracle loop
+    (per-step UNet noise of ~2e-3 accumulated through the inverse-DDIM recurrence), toy UNet, cfg 1.0"""
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    o, eng = _pair()
+    g = torch.Generator().manual_seed(50)
+    f, h, w = 3, 8, 8
+    c = _cond(g, 1, f, h, w)
+    x0 = torch.randn(1, 4, f, h, w, generator=g).half()
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=True)
+    inv = pipe.invert(height=h * 8, width=w * 8, num_frames=f, num_inference_steps=50, guidance_scale=1.0, target_fps=8,
+                      latents=x0.cuda(), prompt_embeds=c["pe"].cuda(), negative_prompt_embeds=c["ne"].cuda(),
+                      image_embeddings=c["ie"].cuda(), image_latents=c["il"].cuda(), return_dict=False, output_dir=None)
+
+    def unet_fn(inp, t):
+        return o(inp.float(), int(t), torch.tensor([8]), c["il"].float(), c["ie"].float(), c["pe"].float())[0].half()
+
+    _, ref = loops_ref.invert_loop(unet_fn, sched_ref.DDIMInverseSchedulerRef(), x0, 50, 1.0)
+    assert inv.shape == ref.shape == (1, 50, 4, f, h, w)
+    got, want = inv[0, 0].float().cpu(), ref[0, 0].float()  # the noisiest latent: end of the recurrence
+    rel = float((got - want).norm() / want.norm())
+    assert rel <= 2e-2, rel
+    first = float((inv[0, -1].float().cpu() - ref[0, -1].float()).norm() / ref[0, -1].float().norm())
+    assert first <= 2e-3, first  # after one step
