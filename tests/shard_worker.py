@@ -89,17 +89,10 @@ def unet(out_dir, which):
             parts = FrameShard().all_gather(got)
             assert all(torch.equal(parts[0], parts[r]) for r in range(world)), f"{name}: ranks disagree"
 
-    if which == "full":
-        compare("full_b1", 1, 16, 32, 32, False)
-    else:
-        F = 4 * world
-        compare("plain_b1", 1, F, 16, 16, False)
-        compare("multiframe_b2", 2, F, 16, 16, True)
-        # composition step: batch of 5 with every injection site live (soft temporal masks at a different resolution
-        # than some feature maps -> the nearest resize of the pixel-sharded masks is exercised)
-        g = torch.Generator().manual_seed(5)
-        hard = (torch.rand(2, 1, 1, F, 16, 16, generator=g) > 0.5).expand(2, 1, 4, F, 16, 16)
-        soft = (torch.randint(0, 256, (2, 1, 1, F, 16, 16), generator=g).float() / 255).half().expand(2, 1, 4, F, 16, 16)
+    def pnp_hooks(F, hw_, seed):
+        g = torch.Generator().manual_seed(seed)
+        hard = (torch.rand(2, 1, 1, F, hw_, hw_, generator=g) > 0.5).expand(2, 1, 4, F, hw_, hw_)
+        soft = (torch.randint(0, 256, (2, 1, 1, F, hw_, hw_), generator=g).float() / 255).half().expand(2, 1, 4, F, hw_, hw_)
         masks = [(soft[j].contiguous().to(dev), hard[j].contiguous().to(dev)) for j in range(2)]
 
         class Pipe:
@@ -113,7 +106,18 @@ def unet(out_dir, which):
             pnp_utils.register_out_conv_injection(Pipe, sched)
             pnp_utils.register_resnet_injection(Pipe, sched)
             pnp_utils.register_time_all(Pipe, 500, masks)
+        return hooks
 
+    if which == "full":
+        compare("full_b1", 1, 16, 32, 32, False)
+        compare("full_pnp_b5", 5, 8, 32, 32, False, pnp_hooks(8, 32, 6))  # composition-shaped step at production widths
+    else:
+        F = 4 * world
+        compare("plain_b1", 1, F, 16, 16, False)
+        compare("multiframe_b2", 2, F, 16, 16, True)
+        # composition step: batch of 5 with every injection site live (soft temporal masks at a different resolution
+        # than some feature maps -> the nearest resize of the pixel-sharded masks is exercised)
+        hooks = pnp_hooks(F, 16, 5)
         compare("pnp_b5", 5, F, 16, 16, True, hooks)
     json.dump(report, open(os.path.join(out_dir, f"unet_r{rank}.json"), "w"))
 

@@ -82,7 +82,7 @@ def test_sharded_forward_full_network_world2(tmp_path):
     r = launch(2, 29553, "unet", str(tmp_path), "full")
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     rep = json.load(open(tmp_path / "unet_r0.json"))
-    assert check(rep) == 2, rep
+    assert check(rep) == 4, rep  # plain batch 1 and a composition-shaped PnP batch of 5, two exchange forms each
 
 
 def test_sharded_inversion_loop_world2(tmp_path):
