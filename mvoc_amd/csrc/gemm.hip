@@ -1091,12 +1091,13 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       // `slots` resident blocks; a partly filled last wave costs 0.3 + 0.7 * fill of a full one (a full one for the 8-wave tiles).
       static const struct { int tile, bn, bm, slots; float rate; } cand[] = {
           {12, 160, 128, 512, 950.f}, {11, 128, 128, 512, 890.f}, {64, 160, 256, 512, 1090.f},
-          {66, 320, 256, 256, 1170.f}, {67, 256, 256, 256, 1020.f}};
+          {66, 320, 256, 256, 1200.f}, {67, 256, 256, 256, 1180.f}};
       const bool can_split = d->workspace && d->split_k == 0 && !d->ln_rowsum;
       double best = 0;
       for (const auto& c : cand) {
         if (d->n % c.bn) continue;
-        if (c.bm == 256 && (d->m < 65536 || !stats_precomputed)) continue;  // measured: below 64 K rows their tails cost more than the model says
+        // measured: below 64 K rows the 256-row tiles' tails cost more than the model says, except 256x256 on deep K
+        if (c.bm == 256 && (!stats_precomputed || (d->m < 65536 && !(c.tile == 67 && d->m >= 16384 && (d->k >= 2560 || d->n >= 2560))))) continue;
         const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn);
         int sk = 1;
         if (can_split && blocks < 384 && c.bm == 128)
@@ -1211,10 +1212,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 66:
       MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
                    "gemm: tile 66 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
-      return launch_glds<2, 4, 5, 2, 2, 0, 32>(a, s);  // 320 x 256
+      return launch_glds<2, 4, 5, 2, 2, 0, 64>(a, s);  // 320 x 256, K step 64: one 147 KB block per CU (2-5 % over K step 32)
     case 67:
       MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 67 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<2, 4, 4, 2, 2, 0, 32>(a, s);  // 256 x 256
+      return launch_glds<2, 4, 4, 2, 2, 0, 64>(a, s);  // 256 x 256, K step 64 (128 KB)
     default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
   }
 }
