@@ -96,3 +96,26 @@ def test_latent_cache_roundtrip(tmp_path):
     assert torch.equal(c2.get(str(tmp_path / "d"), 981), x)
     with pytest.raises(AssertionError):
         c2.get(str(tmp_path / "d"), 961)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """the bench.py JSON line committed with the round's profiles carries every field of the measurement contract"""
+    prof = os.path.join(REPO, "profiles")
+    rnd = sorted(d for d in os.listdir(prof) if os.path.isdir(os.path.join(prof, d)))[-1]
+    files = sorted(f for f in os.listdir(os.path.join(prof, rnd)) if f.endswith("_bench.json"))
+    assert files, "no committed bench line"
+    j = json.load(open(os.path.join(prof, rnd, files[-1])))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["unit"] == "steps/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == "f16" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == j["unit"]
+    assert abs(j["value"] - j["n_gpus"] * j["steps"] / (j["ms_per_step"] * j["steps"] / 1e3)) / j["value"] < 1e-3
