@@ -120,17 +120,23 @@ def main(template_config, configs_list, device, synthetic=False, frame_shard=Non
         if recon.enable_recon:
             ddim_scheduler.set_timesteps(recon.n_steps)
             t0 = ddim_scheduler.timesteps[recon.ddim_init_latents_t_idx]
-            lat = load_ddim_latents_at_t(int(t0), ddim_latents_path=recon.ddim_latents_path)
+            # the start latent comes from the in-HBM latent cache when this process produced it (every rank of a frame
+            # shard holds it; only rank 0's writer thread touches the files), from disk otherwise
+            lat = pipe.latent_cache.get(recon.ddim_latents_path, int(t0))
+            is_writer = frame_shard is None or frame_shard.rank == 0  # all ranks compute; one writes the outputs
             try:
                 video = ddim_sampling(recon, first_frame, lat, pipe, ddim_scheduler, recon.ddim_init_latents_t_idx, g)
-                os.makedirs(config.output_dir, exist_ok=True)
-                export_to_gif(video, os.path.join(config.output_dir, "ddim_reconstruction.gif"))
+                if is_writer:
+                    os.makedirs(config.output_dir, exist_ok=True)
+                    export_to_gif(video, os.path.join(config.output_dir, "ddim_reconstruction.gif"))
             except NotImplementedError as e:  # no VAE decoder on this path: keep the reconstructed latents instead
                 logger.warning(f"reconstruction decoded to latents only ({e})")
                 video = ddim_sampling(recon, first_frame, lat, pipe, ddim_scheduler, recon.ddim_init_latents_t_idx, g, "latent")
-                os.makedirs(config.output_dir, exist_ok=True)
-                torch.save(video.cpu(), os.path.join(config.output_dir, "ddim_reconstruction_latents.pt"))
-
+                if is_writer:
+                    os.makedirs(config.output_dir, exist_ok=True)
+                    torch.save(video.cpu(), os.path.join(config.output_dir, "ddim_reconstruction_latents.pt"))
+        if frame_shard is not None:
+            frame_shard.barrier()  # rank 0's files of this entry are complete before any rank moves on
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -19,8 +19,8 @@ K/V gather.  The only other collective is the 12 x B x groups-byte all-gather of
                     pair of GPUs has its own link, so all seven transfers of a rank proceed concurrently.
   * ``"allgather"`` RCCL all-gather of the whole tensor, then each rank keeps its pixel slab (the form BASELINE.json
                     names for temporal attention).  N x the bytes of ``a2a``; kept for comparison on the 8-GPU node.
-With the ``gloo`` backend (CPU tests, or two test processes sharing one GPU) the same calls are staged through host
-memory and the all-to-all is emulated by an all-gather; results are identical by construction.
+With the ``gloo`` backend (CPU tests, or two test processes sharing one GPU) the same collectives
+(``all_to_all_single`` / ``all_gather``) run on host copies of the tensors.
 
 Pure torch + torch.distributed (no HIP kernels): the exchanges are importable and testable on a CPU-only machine.
 """
@@ -57,6 +57,9 @@ class FrameShard:
         n = hw // self.world
         return self.rank * n, (self.rank + 1) * n
 
+    def barrier(self):
+        dist.barrier(group=self.group)
+
     # ---- collectives (device tensors with nccl; staged through the host with gloo) -------------------
     def _staged(self, t):
         return self.backend == "gloo" and t.is_cuda
@@ -75,12 +78,13 @@ class FrameShard:
         """send [world, ...]: slice j goes to rank j -> recv [world, ...]: slice i came from rank i"""
         send = send.contiguous()
         assert send.shape[0] == self.world
-        if self.exchange == "allgather" or self.backend == "gloo":
+        if self.exchange == "allgather":
             return self.all_gather(send)[:, self.rank].contiguous()
         self.bytes_sent += send.numel() * send.element_size() * (self.world - 1) // self.world
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv
+        src = send.cpu() if self._staged(send) else send  # gloo: the same collective on host tensors
+        recv = torch.empty_like(src)
+        dist.all_to_all_single(recv, src, group=self.group)
+        return recv.to(send.device) if self._staged(send) else recv
 
     # ---- layout exchanges on canonical rows [B * frames * pixels, C] ----------------------------------
     def to_pixel_shard(self, x, batch, frames_local, hw):

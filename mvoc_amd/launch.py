@@ -37,4 +37,11 @@ def pick_device(template_device, shard=None):
         return torch.device(template_device)
     idx = int(os.environ.get("LOCAL_RANK", i))
     ndev = torch.cuda.device_count()
-    return torch.device("cuda", idx % max(ndev, 1))
+    if idx >= max(ndev, 1):
+        # more ranks than GPUs: refuse rather than silently stacking two shards on one device (one process per GPU);
+        # the one-GPU test boxes opt in explicitly
+        if os.environ.get("MVOC_ALLOW_GPU_SHARING") != "1":
+            raise RuntimeError(f"rank with LOCAL_RANK / shard index {idx} has no GPU of its own ({ndev} visible); "
+                               "launch at most one process per GPU (or set MVOC_ALLOW_GPU_SHARING=1 for tests)")
+        idx %= max(ndev, 1)
+    return torch.device("cuda", idx)

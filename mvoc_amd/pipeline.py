@@ -119,6 +119,7 @@ class I2VGenXLPipeline:
         self.vae_scale_factor = 8
         self._guidance_scale = 1.0
         self._graphs = {}
+        self.max_cached_graphs = 4
         self.latent_cache = LatentCache(unet.device)
 
     # ---- reference plumbing ------------------------------------------------------------------------
@@ -204,26 +205,41 @@ class I2VGenXLPipeline:
 
     # ---- one loop iteration each (static buffers so that they can be graph-captured) -------------------
     def _make_stock_step(self, key, latents, cond, guidance_scale):
-        """iteration of invert / __call__: [cat x2] -> UNet -> CFG + (inverse-)DDIM update, in place on `state`"""
+        """iteration of invert / __call__: [cat x2] -> UNet -> CFG + (inverse-)DDIM update, in place on `state`.
+        The conditioning lives in buffers owned by the state (``load_cond`` refreshes them), so one captured iteration
+        serves every later call of the same shape."""
         st = {"latents": latents.clone(), "t": torch.zeros(1, dtype=torch.float32, device=self.device),
-              "coef": torch.zeros(5, dtype=torch.float32, device=self.device)}
+              "coef": torch.zeros(5, dtype=torch.float32, device=self.device),
+              "cond": {k: v.clone() for k, v in cond.items()}}
         do_cfg = guidance_scale > 1
+        own = st["cond"]
         # loop-invariant conditioning (context tokens, cross-attention K/V, image-latent stem): once per loop, not per step
         shape = (latents.shape[0] * (2 if do_cfg else 1),) + tuple(latents.shape[1:])
-        prepared = self.unet.prepare_conditioning(shape, cond["fps"], cond["image_latents"], cond["image_latents"],
-                                                  cond["image_embeddings"], cond["encoder_hidden_states"], False)
+
+        def prepare():
+            return self.unet.prepare_conditioning(shape, own["fps"], own["image_latents"], own["image_latents"],
+                                                  own["image_embeddings"], own["encoder_hidden_states"], False)
+
+        prepared = prepare()
+
+        def load_cond(new):
+            """new conditioning of the same shapes -> the state's static buffers (no re-capture)"""
+            for k, v in new.items():
+                own[k].copy_(v)
+            prepared.copy_from(prepare())
 
         def body():
             x = st["latents"]
             inp = torch.cat([x, x]) if do_cfg else x
-            noise = self.unet.forward(inp, st["t"], cond["fps"], image_latents=cond["image_latents"],
-                                      image_embeddings=cond["image_embeddings"],
-                                      encoder_hidden_states=cond["encoder_hidden_states"], conditioning=prepared)[0]
+            noise = self.unet.forward(inp, st["t"], own["fps"], image_latents=own["image_latents"],
+                                      image_embeddings=own["image_embeddings"],
+                                      encoder_hidden_states=own["encoder_hidden_states"], conditioning=prepared)[0]
             if do_cfg:
                 ops.ddim_step(x, noise[1:2].contiguous(), st["coef"], v_uncond=noise[0:1].contiguous(), out=x)
             else:
                 ops.ddim_step(x, noise, st["coef"], out=x)
 
+        st["load_cond"] = load_cond
         st["run"] = GraphedStep(body, preserve=(st["latents"],)) if self.use_graphs else body
         return st
 
@@ -232,11 +248,17 @@ class I2VGenXLPipeline:
         sched.set_timesteps(num_inference_steps, device=self.device)
         sched.timesteps = sched.timesteps[first_idx:]
         table, index = sched.coef_table(self.device, guidance_scale)
-        key = ("stock", tuple(latents.shape), guidance_scale > 1, type(sched).__name__,
-               tuple(t.data_ptr() for t in cond.values()))
+        # keyed by what the captured iteration bakes in (shapes, CFG layout, frame shard, graphs on/off) -- NOT by the
+        # conditioning tensors' addresses: those change with every invert() / __call__()
+        key = ("stock", tuple(latents.shape), guidance_scale > 1, id(self.unet.shard), bool(self.use_graphs),
+               tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
         st = self._graphs.get(key)
         if st is None:
+            if len(self._graphs) >= self.max_cached_graphs:  # each entry pins a UNet graph + its private activation pool
+                self._graphs.pop(next(iter(self._graphs)))
             st = self._graphs[key] = self._make_stock_step(key, latents, cond, guidance_scale)
+        else:
+            st["load_cond"](cond)
         st["latents"].copy_(latents)
         for i, t in enumerate(sched.timesteps):
             st["t"].fill_(float(t))
@@ -360,15 +382,16 @@ class I2VGenXLPipeline:
         st["t"].fill_(float(t))
         st["coef"].copy_(table_row)
         register_time_all(self, int(t), st["masks"])
-        u = self.unet
-        flags = (u.conv_out.injecting(), u.up_blocks[-1].attentions[0].transformer_blocks[0].attn1.processor.injecting(),
-                 u.up_blocks[-1].temp_attentions[0].transformer_blocks[0].attn1.processor.injecting())
         if not self.use_graphs:
             st["body"]()
             return
-        g = st["variants"].get(flags)
+        # a captured iteration bakes in EVERY site's injecting() decision (the reference allows a schedule per site) and
+        # the device copies of the masks: both are part of the variant key
+        u = self.unet
+        vkey = (u.injection_flags(), u.mask_key(st["masks"]))
+        g = st["variants"].get(vkey)
         if g is None:
-            g = st["variants"][flags] = GraphedStep(st["body"], preserve=(st["latents"],))
+            g = st["variants"][vkey] = GraphedStep(st["body"], preserve=(st["latents"],))
         g()
 
     @torch.no_grad()

@@ -378,6 +378,16 @@ class Conditioning:
     def __init__(self, ctx, stem8, geometry, frames, key):
         self.ctx, self.stem8, self.geometry, self.frames, self.key = ctx, stem8, geometry, frames, key
 
+    def copy_from(self, other):
+        """refresh this (graph-captured) conditioning in place from a freshly prepared one of the same shapes"""
+        if other.key != self.key or set(other.ctx.kv) != set(self.ctx.kv):
+            raise RuntimeError(f"Conditioning.copy_from: prepared for {other.key}, this one for {self.key}")
+        self.ctx.tokens.copy_(other.ctx.tokens)
+        self.stem8.copy_(other.stem8)
+        for k, v in self.ctx.kv.items():
+            v.copy_(other.ctx.kv[k])
+        return self
+
 
 class I2VGenXLUNet:
     """MI355X engine with the reference UNet's call protocol."""
@@ -391,7 +401,7 @@ class I2VGenXLUNet:
             torch.cuda.set_device(self.device)
         self.dtype = H16
         self.num_upsamplers = len(self.config.block_out_channels) - 1
-        self._mask_cache = (None, None)
+        self._mask_cache = (None, None, None)
         self._section_mask_cache = {}
         self._loaded = False
         self.shard = None  # mvoc_amd.frame_shard.FrameShard: frame-axis shard of one long clip (set_frame_shard)
@@ -401,7 +411,7 @@ class I2VGenXLUNet:
         inputs, computes its F/world frames (temporal sections pixel-sharded, see that module) and returns the FULL
         output (one all-gather of the 4-channel prediction), so the loops around the UNet stay unchanged."""
         self.shard = shard
-        self._mask_cache = (None, None)
+        self._mask_cache = (None, None, None)
         self._section_mask_cache = {}
         return self
 
@@ -526,8 +536,10 @@ class I2VGenXLUNet:
         return self._all_frame_masks(mask_list)[2:]
 
     def _all_frame_masks(self, mask_list):
-        """(soft, hard) over ALL frames, then the slices of this rank's frames (the same tensors without a frame shard)"""
-        key = tuple((m[0].data_ptr(), m[1].data_ptr()) for m in mask_list)
+        """(soft, hard) over ALL frames, then the slices of this rank's frames (the same tensors without a frame shard).
+        The cache holds a reference to the source tensors and their versions: a freed-and-reallocated mask set (same
+        addresses from the caching allocator) or an in-place edit of ``obj_masks_tensors`` cannot hit a stale entry."""
+        key = self.mask_key(mask_list)
         if self._mask_cache[0] != key:
             soft = torch.stack([m[0].reshape(-1, *m[0].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
             hard = torch.stack([m[1].reshape(-1, *m[1].shape[-3:])[0] for m in mask_list]).to(self.device, H16).contiguous()
@@ -535,9 +547,27 @@ class I2VGenXLUNet:
             if self.shard is not None:
                 f0, f1 = self.shard.frame_range(soft.shape[1])
                 lsoft, lhard = soft[:, f0:f1].contiguous(), hard[:, f0:f1].contiguous()
-            self._mask_cache = (key, (soft, hard, lsoft, lhard))
+            keep = [(m[0], m[1]) for m in mask_list]  # ids stay unique for as long as the entry lives
+            self._mask_cache = (key, (soft, hard, lsoft, lhard), keep)
             self._section_mask_cache = {}
         return self._mask_cache[1]
+
+    @staticmethod
+    def mask_key(mask_list):
+        return tuple((id(m[0]), m[0]._version, id(m[1]), m[1]._version) for m in mask_list)
+
+    def hook_sites(self):
+        """every node whose ``injecting()`` decision shapes a forward (the sites ``pnp_utils.register_*`` may address)"""
+        sites = [self.conv_out]
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            sites += list(blk.resnets) + list(blk.temp_convs)
+            for tr in list(blk.attentions) + list(blk.temp_attentions):
+                sites.append(tr.transformer_blocks[0].attn1.processor)
+        return sites
+
+    def injection_flags(self):
+        """the per-site injecting() bits of the CURRENT hook state: what a captured iteration bakes in"""
+        return tuple(bool(s.injecting()) for s in self.hook_sites())
 
     def section_masks(self, mask_list, kind, full_hw):
         """masks for a temporal section (kind 0 = soft, 1 = hard): all frames.  Frame-sharded, the section sees a slab of

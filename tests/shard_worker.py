@@ -53,7 +53,7 @@ def unet(out_dir, which):
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda:0"
     # the 4-level toy of the oracle tests (full attribute tree the hooks address) or the production network
-    cfg = UNetConfig() if which == "full" else UNetConfig(
+    cfg = UNetConfig() if which in ("full", "cfg4") else UNetConfig(
         block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
         attention_head_dim=64, transformer_in_heads=2, context_pool=8)
     eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
@@ -69,9 +69,9 @@ def unet(out_dir, which):
         return eng.forward_ext(x["sample"], torch.tensor([500.0]).to(dev), x["fps"], x["first"], x["lat"], x["emb"], x["ehs"],
                                multi_frame_guidance=mfg)[0].float()
 
-    def compare(name, B, F, h, w, mfg, hooks=None):
+    def compare(name, B, F, h, w, mfg, hooks=None, modes=("a2a", "allgather")):
         x = inputs(B, F, h, w, seed=B * 100 + F)
-        for mode in ("a2a", "allgather"):
+        for mode in modes:
             eng.set_frame_shard(None)
             if hooks:
                 hooks()
@@ -108,7 +108,10 @@ def unet(out_dir, which):
             pnp_utils.register_time_all(Pipe, 500, masks)
         return hooks
 
-    if which == "full":
+    if which == "cfg4":
+        # BASELINE configs[3] at its real size: 32 frames, 768x768 -> 96x96 latents (294 912 rows at L0), all-to-all form
+        compare("cfg4_b1", 1, 32, 96, 96, False, modes=("a2a",))
+    elif which == "full":
         compare("full_b1", 1, 16, 32, 32, False)
         compare("full_pnp_b5", 5, 8, 32, 32, False, pnp_hooks(8, 32, 6))  # composition-shaped step at production widths
     else:

@@ -85,6 +85,14 @@ def test_sharded_forward_full_network_world2(tmp_path):
     assert check(rep) == 4, rep  # plain batch 1 and a composition-shaped PnP batch of 5, two exchange forms each
 
 
+def test_sharded_forward_cfg4_size_world2(tmp_path):
+    """BASELINE configs[3] at its real size (32 frames x 768x768, 1.42 B network), two ranks, all-to-all exchanges"""
+    r = launch(2, 29555, "unet", str(tmp_path), "cfg4", timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.load(open(tmp_path / "unet_r0.json"))
+    assert check(rep) == 1, rep
+
+
 def test_sharded_inversion_loop_world2(tmp_path):
     """pipe.invert on a frame-sharded UNet: same latents as the single-GPU loop (5 steps, cfg 7.5: <= 3e-2 like the
     loop-vs-oracle tests; observed 2e-2: cfg 7.5 amplifies the per-forward 2e-3), one set of ddim_latents files written by rank 0"""

@@ -1,0 +1,234 @@
+"""GPU: the HIP engine against the CPU oracle at PRODUCTION channel widths -- the 1.42 B-parameter I2VGen-XL architecture
+(default ``UNetConfig``: 320/640/1280/1280 channels, 5/10/20 heads, 1024-wide context, 32 groups) with identical
+fp16-rounded weights on both sides, at latent sizes the oracle finishes in seconds (32x32: L0 has 16 384-20 480 rows, so the
+GEMM dispatcher takes its large-M branches: the 256-row 8-wave tiles, K-step-32 tiles, split-K, LayerNorm folding at
+C = 320/640/1280, two-source gathers at 1280+640 / 640+320, the 5-D GroupNorms over 32 groups).
+
+  (a) stock ``I2VGenXLUNet.forward`` (invert / __call__ protocol), B=1, F=16, 32x32          pipeline_i2vgen_xl.py:1952-1961
+  (b) ``I2VGenXLUnetExtension.forward`` B=5, F=4, 32x32 with all five hook families live      pipeline_i2vgen_xl.py:109-362,
+      at t=981 (feature + attention injection) and t=861 (attention injection only)           pnp_utils.py:565-1146
+  (c) one inversion step and one composition step through ``mvoc_amd.pipeline``               pipeline_i2vgen_xl.py:1940-2000,
+      against ``oracle/loops_ref.py``                                                          1636-1734
+  (d) BASELINE configs[0]: 8 frames, 256x256 (32x32 latents), 10-step DDIM inversion, HIP loop vs oracle loop
+
+Tolerances are SURVEY section 8d's: one UNet forward rel-L2 <= 3e-3 and max-abs <= 2e-2 * max|ref|; latents after one DDIM
+step rel-L2 <= 2e-3; after the 10-step loop <= 1e-2 (8d allows 2e-2 after 50 steps; the drift is roughly linear in steps)."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+REL_L2_FWD, MAX_ABS_FWD = 3e-3, 2e-2
+REL_L2_STEP = 2e-3
+H, W = 32, 32
+
+
+def build_oracle(seed=77):
+    """the oracle tree at production widths with seeded, fp16-representable weights (meta construction skips the
+    throw-away default init of 1.42 B parameters)"""
+    from oracle import unet_ref as U
+    with torch.device("meta"):
+        o = U.I2VGenXLUNet(U.UNetConfig())
+    o = o.to_empty(device="cpu")
+    U.init_weights_(o, seed=seed)
+    for p in o.parameters():
+        p.copy_(p.half().float())
+    return o
+
+
+@pytest.fixture(scope="module")
+def trio():
+    """(oracle, engine, oracle hook state): the oracle's PnP hooks are installed once; with every schedule None they
+    are the stock forwards"""
+    from oracle.pnp_model_ref import PnPState, install_pnp
+    from mvoc_amd.unet import I2VGenXLUNet
+    o = build_oracle()
+    eng = I2VGenXLUNet(o.config.to_dict()).load_state_dict(o.state_dict())
+    pst = PnPState()
+    install_pnp(o, pst)
+    return o, eng, pst
+
+
+@pytest.fixture
+def pair(trio):
+    o, eng, pst = trio
+    yield o, eng
+    pst.conv_schedule = pst.spatial_schedule = pst.temporal_schedule = None
+    pst.t = pst.masks = None
+    for site in eng.hook_sites():
+        site.injection_schedule, site.t, site.mask = None, None, None
+
+
+def _metrics(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    return float((out - ref).norm() / ref.norm()), float((out - ref).abs().max() / ref.abs().max())
+
+
+def _inputs(g, b, f):
+    r = lambda *s: torch.randn(*s, generator=g).half().float()
+    return dict(sample=r(b, 4, f, H, W), il1=0.5 * r(b, 4, f, H, W), il=0.5 * r(b, 4, f, H, W), ie=r(b, f, 1024), eh=r(b, 77, 1024),
+                fps=torch.tensor([8] * b))
+
+
+def _masks(g, f):
+    """two moving-rectangle objects with soft edges (uint8 levels like a resized PNG mask)"""
+    u8 = torch.zeros(2, f, H, W)
+    for j in range(2):
+        for k in range(f):
+            y0, x0 = 4 + 9 * j + k, 3 + 11 * j + 2 * k
+            u8[j, k, y0:y0 + 10, x0:x0 + 9] = 255
+            u8[j, k, y0 - 1, x0:x0 + 9] = 96  # soft border: float mask 96/255, bool mask True
+            u8[j, k, y0 + 10, x0:x0 + 9] = 7   # below the >10 threshold: float 7/255, bool False
+    return [((u8[j] / 255).half()[None, None].repeat(1, 4, 1, 1, 1), (u8[j] > 10)[None, None].repeat(1, 4, 1, 1, 1)) for j in range(2)]
+
+
+def test_stock_forward_full_width(pair):
+    o, eng = pair
+    g = torch.Generator().manual_seed(1)
+    x = _inputs(g, 1, 16)
+    ref = o(x["sample"], 501, x["fps"], x["il"], x["ie"][:, :1], x["eh"])[0]
+    out = eng(x["sample"], 501, x["fps"], image_latents=x["il"], image_embeddings=x["ie"][:, :1], encoder_hidden_states=x["eh"])[0]
+    rel, mx = _metrics(out, ref)
+    print(f"full-width stock forward B=1 F=16 {H}x{W}: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}")
+    assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD, (rel, mx)
+
+
+def _register_all(pipe, hip_ts):
+    from mvoc_amd import pnp_utils
+    pnp_utils.modify_diffuser_attention_forward(pipe.unet)
+    pnp_utils.register_temp_attention_pnp(pipe, hip_ts[:50], False)
+    pnp_utils.register_spatial_attention_pnp(pipe, hip_ts[:50], False)
+    pnp_utils.register_temp_conv_injection(pipe, hip_ts[:5])
+    pnp_utils.register_out_conv_injection(pipe, hip_ts[:5])
+    pnp_utils.register_resnet_injection(pipe, hip_ts[:5])
+
+
+def _oracle_hooks_on(pst, rs):
+    pst.conv_schedule, pst.spatial_schedule, pst.temporal_schedule = rs.timesteps[:5], rs.timesteps[:50], rs.timesteps[:50]
+    return pst
+
+
+def test_ext_forward_with_all_hooks_full_width(pair, trio):
+    from oracle import sched_ref
+    from mvoc_amd import pnp_utils
+    from mvoc_amd.schedulers import DDIMScheduler
+    o, eng = pair
+    st = trio[2]
+    g = torch.Generator().manual_seed(2)
+    f = 4
+    x = _inputs(g, 5, f)
+    masks = _masks(g, f)
+    rs = sched_ref.DDIMSchedulerRef()
+    rs.set_timesteps(50)
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    _oracle_hooks_on(st, rs)
+    pipe = types.SimpleNamespace(unet=eng)
+    _register_all(pipe, s.timesteps)
+    for t in (981, 861):
+        st.t, st.masks = t, masks
+        ref = o.forward_ext(x["sample"], t, x["fps"], x["il1"], x["il"], x["ie"], x["eh"])[0]
+        pnp_utils.register_time_all(pipe, t, masks)
+        out = eng.forward_ext(x["sample"], t, x["fps"], x["il1"], x["il"], x["ie"], x["eh"])[0]
+        rel, mx = _metrics(out, ref)
+        print(f"full-width ext forward B=5 F={f} t={t}: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}")
+        assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD, (t, rel, mx)
+        if t == 981:  # conv_out injection: chunks 3 and 4 leave the network identical (SURVEY B-5)
+            assert torch.equal(out[3], out[4])
+
+
+def test_one_inversion_and_one_composition_step_full_width(pair, trio):
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler, DDIMScheduler
+    o, eng = pair
+    g = torch.Generator().manual_seed(3)
+    f = 4
+    # ---- one inverse-DDIM step (cfg 1.0), t = 1 -> 21 on the 50-step inverse schedule --------------------------
+    x = _inputs(g, 1, f)
+    x0 = x["sample"].half()
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=False)
+    pipe.latent_cache.write_files = False
+    cond = dict(encoder_hidden_states=x["eh"].half().cuda(), image_embeddings=x["ie"][:, :1].half().cuda(),
+                image_latents=x["il"].half().cuda(), fps=torch.full((1,), 8.0, device="cuda"))
+    sched = pipe.scheduler
+    sched.set_timesteps(50, device="cuda")
+    table, index = sched.coef_table(eng.device, 1.0)
+    st = pipe._make_stock_step("t", x0.cuda(), cond, 1.0)
+    t = int(sched.timesteps[0])
+    st["t"].fill_(float(t))
+    st["coef"].copy_(table[index[t]])
+    st["run"]()
+    rsi = sched_ref.DDIMInverseSchedulerRef()
+    rsi.set_timesteps(50)
+    assert int(rsi.timesteps[0]) == t
+    noise = o(x0.float(), t, x["fps"], x["il"], x["ie"][:, :1], x["eh"])[0].half()
+    ref = loops_ref.scheduler_step_5d(rsi, noise, t, x0)
+    rel, _ = _metrics(st["latents"], ref)
+    print(f"full-width inversion step t={t}: latents rel-L2 {rel:.2e}")
+    assert rel <= REL_L2_STEP, rel
+    # ---- one composition step (batch 5, every hook family live, CFG 9.0, DDIM update) at t = 981 -------------------
+    y = _inputs(g, 5, f)
+    masks = _masks(g, f)
+    s = DDIMScheduler()
+    s.set_timesteps(50, device="cuda")
+    rs = sched_ref.DDIMSchedulerRef()
+    rs.set_timesteps(50)
+    pst = _oracle_hooks_on(trio[2], rs)
+    pipe = I2VGenXLPipeline(eng, s, use_graphs=False)
+    _register_all(pipe, s.timesteps)
+    if True:
+        lat = y["sample"][4:5].half()
+        src = [y["sample"][k:k + 1].half() for k in range(3)]
+        ccond = dict(encoder_hidden_states=y["eh"].half().cuda(), image_embeddings=y["ie"].half().cuda(),
+                     image_latents_first=y["il1"].half().cuda(), image_latents=y["il"].half().cuda(),
+                     fps=torch.full((5,), 8.0, device="cuda"))
+        cst = pipe.make_composition_state(lat.cuda(), ccond, masks, 9.0)
+        ctable, cindex = s.coef_table(eng.device, 9.0)
+        pipe.composition_step(cst, 981, src[0].cuda(), [src[1].cuda(), src[2].cuda()], ctable[cindex[981]], None)
+        pst.t, pst.masks = 981, masks
+        inp = torch.cat(src + [lat, lat]).float()
+        rn = o.forward_ext(inp, 981, y["fps"], y["il1"], y["il"], y["ie"], y["eh"])[0].half()
+        ref = loops_ref.scheduler_step_5d(rs, loops_ref.cfg_combine(rn[3:4], rn[4:5], 9.0), 981, lat)
+        rel, _ = _metrics(cst["latents"], ref)
+        print(f"full-width composition step t=981: latents rel-L2 {rel:.2e}")
+        assert rel <= 3e-3, rel  # CFG 9.0 amplifies the (cond - uncond) difference of two fp16 predictions
+
+
+def test_cfg1_8frame_256sq_10step_inversion(pair, tmp_path):
+    """BASELINE.json configs[0]: a single 8-frame 256x256 clip, 10-step DDIM inversion -- the HIP loop (graph replay)
+    against the oracle loop on the same inputs; files and return layout as the reference writes them"""
+    import os
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    o, eng = pair
+    g = torch.Generator().manual_seed(4)
+    f = 8
+    x = _inputs(g, 1, f)
+    x0 = x["sample"].half()
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=True)
+    out_dir = str(tmp_path / "cfg1")
+    inv = pipe.invert(height=H * 8, width=W * 8, num_frames=f, num_inference_steps=10, guidance_scale=1.0, target_fps=8,
+                      latents=x0.cuda(), prompt_embeds=x["eh"].half().cuda(), negative_prompt_embeds=x["eh"].half().cuda(),
+                      image_embeddings=x["ie"][:, :1].half().cuda(), image_latents=x["il"].half().cuda(), return_dict=False,
+                      output_dir=out_dir)
+    assert tuple(inv.shape) == (1, 10, 4, f, H, W)
+
+    def unet_fn(inp, t):
+        return o(inp.float(), int(t), x["fps"], x["il"], x["ie"][:, :1], x["eh"])[0].half()
+
+    saved, ref_seq = loops_ref.invert_loop(unet_fn, sched_ref.DDIMInverseSchedulerRef(), x0, 10, 1.0)
+    assert sorted(saved) == [1 + 100 * k for k in range(10)]
+    assert sorted(os.listdir(out_dir)) == sorted(f"ddim_latents_{t}.pt" for t in saved)
+    worst = 0.0
+    for k in range(10):  # inv[:, 0] is the noisiest latent (pipeline_i2vgen_xl.py:2003)
+        rel, _ = _metrics(inv[:, k], ref_seq[:, k])
+        worst = max(worst, rel)
+    first, _ = _metrics(inv[:, 9], ref_seq[:, 9])
+    print(f"cfg1 (8 x 256x256, 10 steps): rel-L2 after step 1 {first:.2e}, worst over the loop {worst:.2e}")
+    assert first <= REL_L2_STEP and worst <= 1e-2, (first, worst)

@@ -203,3 +203,34 @@ def test_g10_init_pnp_matches_reference():
     bs = golden[0]["hooked"]
     assert bs["conv_out"]["schedule"] == [981, 961, 941, 921, 901] and len(bs) == 23
     assert all(len(v["schedule"]) == 50 for k, v in bs.items() if k.endswith(".processor"))
+
+
+def test_mask_preprocess_matches_g9(golden_dir, tmp_path):
+    """a14: the PRODUCT's ``mvoc_amd.utils.mask_preprocess`` (reference ``utils.py:113-145``) on the boat_surf demo's mask
+    PNGs (shipped as fixture data) against G9 = the reference's own ``mask_preprocess`` output on the same files: native
+    1280x720 -> [1,4,16,90,160], and the 512x512 bench variant -> [1,4,16,64,64]; float = v/255 in fp16, bool = v > 10"""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from mvoc_amd.utils import mask_preprocess
+    g = np.load(os.path.join(golden_dir, "g9_boat_surf_masks.npz"))
+    for name in ("boat_mask", "surf_mask"):
+        src = os.path.join(golden_dir, "boat_surf_masks", name)
+        fl, bl = mask_preprocess(src, "cpu", torch.float16, 1, 4, 16, downscale=8)
+        assert fl.dtype == torch.float16 and bl.dtype == torch.bool and tuple(fl.shape) == tuple(bl.shape) == (1, 4, 16, 90, 160)
+        want = (torch.from_numpy(g[f"{name}_90x160_float_u8"]).float() / 255).half()
+        for c in range(4):  # the same mask repeated over the 4 latent channels
+            assert torch.equal(fl[0, c], want)
+            assert torch.equal(bl[0, c], torch.from_numpy(g[f"{name}_90x160_bool"]))
+        small = tmp_path / name
+        small.mkdir()
+        for i in range(16):
+            Image.open(os.path.join(src, f"{i:05d}.png")).resize((512, 512), Image.NEAREST).save(small / f"{i:05d}.png")
+        fl, bl = mask_preprocess(str(small), "cpu", torch.float16, 1, 4, 16, downscale=8)
+        assert torch.equal(fl[0, 0], (torch.from_numpy(g[f"{name}_64x64_float_u8"]).float() / 255).half())
+        assert torch.equal(bl[0, 0], torch.from_numpy(g[f"{name}_64x64_bool"]))
+    # a single file is repeated over the frames (static variant, utils.py:92-110)
+    one = os.path.join(golden_dir, "boat_surf_masks", "boat_mask", "00003.png")
+    fl, bl = mask_preprocess(one, "cpu", torch.float16, 1, 4, 5, downscale=8)
+    assert tuple(fl.shape) == (1, 4, 5, 90, 160) and all(torch.equal(fl[0, 0, 0], fl[0, 0, k]) for k in range(5))
+    assert torch.equal(bl[0, 0, 0], torch.from_numpy(g["boat_mask_90x160_bool"][3]))

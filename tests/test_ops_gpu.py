@@ -246,6 +246,131 @@ def test_tconv3(ops, frames, tile):
     assert rel_l2(got, ref) < 1.5e-3
 
 
+# ---- production shapes x production tiles --------------------------------------------------------------
+# The tiles the dispatcher selects at the network's real shapes (csrc/gemm.hip: 256-row 8-wave tiles, K-step-32 tiles,
+# 160-wide tiles), forced one by one, in every A-gather mode, at production K (cin 640 / 1280+640 / 3x640) with the
+# time-embedding row add and the residual.  Operands are small integers: every product and every fp32 partial sum is
+# exact and |result| < 2048 is exact in fp16, so the comparison with torch's CPU conv is BIT-EXACT -- any indexing slip in
+# a tile (tap order, source switch, swizzle, tail rows) shows as a wrong integer.
+PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67]
+_prod_cache = {}
+
+
+def _ints(g, shape, lo=-1, hi=1):
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+def _prod_case(name):
+    """(inputs, exact reference) per case, computed once and shared by every tile"""
+    if name in _prod_cache:
+        return _prod_cache[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    if name == "conv640_320":      # up_blocks[3].resnets[0].conv1 shape class at 32x32: M = 16384, K = 5760
+        n, c1, c2, cout, h, w, fr = 16, 640, 0, 320, 32, 32, 16
+    elif name == "conv1280+640_640":  # decoder skip concat (two sources), M = 4096, K = 17280
+        n, c1, c2, cout, h, w, fr = 16, 1280, 640, 640, 16, 16, 16
+    else:
+        raise KeyError(name)
+    x1 = _ints(g, (n, c1, h, w))
+    x2 = _ints(g, (n, c2, h, w)) if c2 else None
+    wt = _ints(g, (cout, c1 + c2, 3, 3))
+    wt[torch.rand(wt.shape, generator=g) < 0.5] = 0  # keep |sum| well inside the fp16-exact range
+    b = _ints(g, (cout,), -4, 4)
+    temb = _ints(g, (n // fr, cout), -4, 4)
+    res = _ints(g, (n, cout, h, w), -4, 4)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin, wt, b, padding=1) + temb.repeat_interleave(fr, 0)[:, :, None, None] + res
+    assert ref.abs().max() < 2048
+    _prod_cache[name] = (dict(n=n, h=h, w=w, fr=fr, cout=cout, x1=dev(_nhwc(x1)), x2=None if x2 is None else dev(_nhwc(x2)),
+                              wt=dev(wt), b=dev(b), temb=dev(temb), res=dev(_nhwc(res))), _nhwc(ref).contiguous())
+    return _prod_cache[name]
+
+
+@pytest.mark.parametrize("tile", PROD_TILES)
+@pytest.mark.parametrize("case", ["conv640_320", "conv1280+640_640"])
+def test_conv3x3_production_tiles_exact(ops, case, tile):
+    from mvoc_amd.unet import pack_conv3x3
+    c, ref = _prod_case(case)
+    out, _, _ = ops.conv3x3(c["x1"], pack_conv3x3(c["wt"]), c["b"], nimg=c["n"], h=c["h"], wd=c["w"], x2=c["x2"], rowadd=c["temb"],
+                            rowadd_div=c["fr"] * c["h"] * c["w"], resid=c["res"], n_store=c["cout"], tile=tile, split_k=1)
+    assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+
+
+@pytest.mark.parametrize("split_k", [0, 2, 4, 8])
+def test_conv3x3_production_split_k_exact(ops, split_k):
+    """the deep-K, few-rows convs of the coarse levels take the split-K path (fp32 slabs + reduce pass)"""
+    from mvoc_amd.unet import pack_conv3x3
+    c, ref = _prod_case("conv1280+640_640")
+    out, _, _ = ops.conv3x3(c["x1"], pack_conv3x3(c["wt"]), c["b"], nimg=c["n"], h=c["h"], wd=c["w"], x2=c["x2"], rowadd=c["temb"],
+                            rowadd_div=c["fr"] * c["h"] * c["w"], resid=c["res"], n_store=c["cout"], split_k=split_k)
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("tile", PROD_TILES)
+def test_tconv3_production_tiles_exact(ops, tile):
+    """(3,1,1) temporal conv at C = 640, 16 frames (frame-boundary zero padding on the first / last frame), + residual"""
+    from mvoc_amd.unet import pack_tconv
+    key = "tconv640"
+    if key not in _prod_cache:
+        g = torch.Generator().manual_seed(640)
+        nb, c, frames, hw = 2, 640, 16, 256
+        x = _ints(g, (nb, c, frames, hw, 1))
+        wt = _ints(g, (c, c, 3, 1, 1))
+        wt[torch.rand(wt.shape, generator=g) < 0.5] = 0
+        b = _ints(g, (c,), -4, 4)
+        ref = F.conv3d(x, wt, b, padding=(1, 0, 0)) + x
+        assert ref.abs().max() < 2048
+        rows = x[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c)
+        _prod_cache[key] = (dict(rows=dev(rows), wt=dev(wt), b=dev(b), nb=nb, frames=frames, hw=hw, c=c),
+                            ref[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c).contiguous())
+    c, ref = _prod_cache[key]
+    out = ops.tconv3(c["rows"], pack_tconv(c["wt"]), c["b"], nvid=c["nb"], frames=c["frames"], hw=c["hw"], resid=c["rows"], tile=tile,
+                     split_k=1)
+    assert torch.equal(out.float().cpu(), ref), f"tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+
+
+@pytest.mark.parametrize("tile", PROD_TILES)
+@pytest.mark.parametrize("m,n,k", [(65536, 320, 320), (16384, 960, 320), (20480, 1280, 1280)])
+def test_linear_production_tiles_exact(ops, m, n, k, tile):
+    """the L0 / L2 projections at their real row counts (all auto-dispatch thresholds crossed), bias + residual"""
+    key = ("lin", m, n, k)
+    if key not in _prod_cache:
+        g = torch.Generator().manual_seed(m + n + k)
+        x, w = _ints(g, (m, k)), _ints(g, (n, k))
+        w[torch.rand(w.shape, generator=g) < 0.5] = 0
+        b, r = _ints(g, (n,), -4, 4), _ints(g, (m, n), -4, 4)
+        _prod_cache[key] = (dev(x), dev(w), dev(b), dev(r), x @ w.t() + b + r)
+    x, w, b, r, ref = _prod_cache[key]
+    out = ops.linear(x, w, b, resid=r, tile=tile)
+    assert torch.equal(out.float().cpu(), ref), f"tile {tile}"
+
+
+@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67])
+@pytest.mark.parametrize("m,c,inner", [(16384, 320, 1280), (4096, 1280, 5120)])
+def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
+    """GEGLU feed-forward entry with the LayerNorm folded in, at C = 320 (L0) and C = 1280 (L2) and production rows, on the
+    GEGLU-capable tiles (even TN); tolerance as test_linear_layernorm_fold"""
+    from mvoc_amd.unet import Linear, pack_geglu
+    key = ("geglu", m, c, inner)
+    if key not in _prod_cache:
+        g = torch.Generator().manual_seed(m + c)
+        x = (torch.randn(m, c, generator=g) * 1.3 + 0.4).half()
+        w = (torch.randn(2 * inner, c, generator=g) / math.sqrt(c)).half()
+        b = torch.randn(2 * inner, generator=g).half()
+        gm, bt = (1 + 0.3 * torch.randn(c, generator=g)).half(), (0.3 * torch.randn(c, generator=g)).half()
+        y = F.layer_norm(x.float(), (c,), gm.float(), bt.float(), 1e-5).half().float() @ w.float().t() + b.float()
+        hh, gg = y.half().float().chunk(2, dim=-1)
+        wp, bp = pack_geglu(dev(w), dev(b))
+        lin = Linear(wp, bp).fold_layernorm(dev(gm), dev(bt))
+        _prod_cache[key] = (dev(x), lin, hh * F.gelu(gg))
+    x, lin, ref = _prod_cache[key]
+    stats = ops.row_stats(x, lin.ln[2])
+    out = ops.linear(x, lin.w_ln, None, n_store=lin.n, ln=lin.ln + (stats,), act=ops.ACT_GEGLU, tile=tile)
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 3e-2 * ref.abs().max()
+
+
 # ---- attention ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tq,tk,heads,kv_bdiv", [(256, 256, 2, 1), (100, 100, 1, 1), (200, 145, 2, 3), (64, 64, 5, 1), (130, 77, 1, 1)])
 def test_flash_attn(ops, tq, tk, heads, kv_bdiv):

@@ -3,8 +3,8 @@ REFERENCE's own ``I2VGenXLUnetExtension.forward`` + PnP hooks (tests/golden/g7_u
 oracle on other shapes (odd sizes, forced upsample size, multi-frame guidance).
 
 Tolerance (fp16 kernels with fp32 accumulation vs an fp32 CPU evaluation of the same fp16-rounded weights):
-rel-L2 <= 5e-3 and max-abs <= 3e-2 * max|ref| for one UNet forward (SURVEY section 8d proposes 3e-3 / 2e-2 for
-the production-size network; the toy network has proportionally larger fp16 rounding noise per channel)."""
+rel-L2 <= 3e-3 and max-abs <= 2e-2 * max|ref| for one UNet forward (the production-width network is
+held to the same numbers in tests/test_fullwidth_gpu.py)."""
 import os
 import types
 
@@ -15,8 +15,8 @@ import torch
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-REL_L2_TOL = 5e-3
-MAX_ABS_TOL = 3e-2
+REL_L2_TOL = 3e-3
+MAX_ABS_TOL = 2e-2
 
 
 def _oracle_small4(seed=9):
@@ -41,6 +41,7 @@ def _close(out, ref, tag=""):
     assert torch.isfinite(out).all(), tag
     rel = float((out - ref).norm() / ref.norm())
     mx = float((out - ref).abs().max() / ref.abs().max())
+    print(f"{tag}: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}")
     assert rel <= REL_L2_TOL and mx <= MAX_ABS_TOL, f"{tag}: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}"
     return rel, mx
 

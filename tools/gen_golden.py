@@ -325,6 +325,18 @@ def gen_masks(ref_utils):
     np.savez_compressed(os.path.join(OUT, "g9_boat_surf_masks.npz"), **out)
 
 
+def copy_mask_pngs():
+    """G9 inputs: the boat_surf demo's 2 x 16 mask PNGs (data files of the reference's demo, 1280x720 palette images,
+    580 KB) so that the PRODUCT's ``mvoc_amd.utils.mask_preprocess`` can be run against G9 on machines without
+    /root/reference (tests/test_host_cpu.py::test_mask_preprocess_matches_g9)"""
+    import shutil
+    for name in ("boat_mask", "surf_mask"):
+        dst = os.path.join(OUT, "boat_surf_masks", name)
+        os.makedirs(dst, exist_ok=True)
+        for i in range(16):
+            shutil.copyfile(os.path.join(REF, "demo", "boat_surf", name, f"{i:05d}.png"), os.path.join(dst, f"{i:05d}.png"))
+
+
 # ---- G8: the three denoising loops, run from the reference's own pipeline methods --------------------------------
 def fake_unet(x, t, ehs, fps, ilf, il, ie):
     """Stand-in for the UNet inside the loops: elementwise fp16 arithmetic only (bit-reproducible on any machine), a
@@ -514,6 +526,8 @@ def gen_init_pnp():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-mask-pngs" in sys.argv:
+        return copy_mask_pngs()
     install_stubs()
     import pnp_utils  # the reference's
     from pipelines import pipeline_i2vgen_xl  # the reference's
@@ -525,6 +539,7 @@ def main():
     gen_transformer_forwards(pnp_utils)
     gen_unet_ext(pnp_utils, pipeline_i2vgen_xl)
     gen_masks(ref_utils)
+    copy_mask_pngs()
     gen_loops(pnp_utils, pipeline_i2vgen_xl)
     gen_init_pnp()
     for f in sorted(os.listdir(OUT)):
