@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvoc_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]
@@ -17,7 +17,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # and needs 162 instead of 196 registers (3 waves per SIMD instead of 2).
 # gemm: neutral for the 32-row-per-wave tiles (same speed, no accvgpr traffic), required by the 64-row-per-wave tiles
 # (160 / 128 accumulator registers + operands fit 256 unified registers only in this form -> 2 waves per SIMD).
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "gemm_pp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _digest():

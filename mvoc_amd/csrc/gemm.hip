@@ -19,37 +19,12 @@
 //   reads are bank-conflict free (stride 20 dwords: 5r mod 16 is a bijection over a 16-lane group).
 // * 1-D grid with an XCD-aware remap: the n-tiles of one m-tile are neighbours on one XCD, so the activation
 //   tile they share is served by that XCD's L2.
-#include "common.h"
+#include "gemm_args.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int ROWB = 80;  // LDS row pitch in bytes (64 B of data + 16 B pad)
-
-struct GemmArgs {
-  const half_t* a;
-  const half_t* a2;
-  const half_t* w;
-  half_t* out;
-  const half_t* bias;
-  const half_t* rowadd;
-  const half_t* resid;
-  int M, N, K, n_store;
-  int ldo, ldr, ld_rowadd, rowadd_div;
-  int a_mode, lda, lda2, c1, cin;
-  int nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
-  float ups_sh, ups_sw;
-  int frames, hw;
-  int act;
-  int n_tiles, m_tiles;
-  const float* ln_s;   // LayerNorm folded into this GEMM: row sums of the gamma-scaled weights (fp32 [N]) or NULL
-  const float* ln_c;   //   beta @ W^T (+ bias), fp32 [N]
-  const float* ln_stats;  // optional precomputed {mean, rstd} per row (fp32 [M][2]); NULL: accumulated in the K loop
-  float ln_eps;
-  int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
-  float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
-  int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
-};
 
 struct RowInfo {   // per staged activation row (fixed for the whole K loop)
   int m;           // global row, -1 if beyond M
@@ -1135,6 +1110,31 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       a.split_k = sk;
       a.k_per_split = (int)(d->k / sk);
       a.ws = (float*)d->workspace;
+    }
+  }
+  // ---- persistent ping-pong kernel (gemm_pp.hip): tiles 91 (256 x 256) / 92 (320 x 256) -----------------------------------
+  {
+    const bool pp_ok = d->k % 32 == 0 && d->cin % 32 == 0 && d->c1 % 32 == 0 && a.epi_lds &&
+                       (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin) && !(d->ln_rowsum && !d->ln_stats);
+    int pp = 0;
+    if (d->tile == 91 || d->tile == 92) {
+      MVOC_REQUIRE(pp_ok && !(d->tile == 92 && d->act == MVOC_ACT_GEGLU), -2,
+                   "gemm: tiles 91 / 92 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
+      pp = d->tile == 91 ? 256 : 320;
+    }
+    if (pp) {
+      a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
+      if (d->split_k > 1 && d->workspace && d->act != MVOC_ACT_GEGLU && !d->ln_rowsum && d->k % (32 * d->split_k) == 0 &&
+          (size_t)d->split_k * d->m * d->n * 4 <= d->workspace_bytes) {
+        a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
+      }
+      const int rc = mvoc_launch_gemm_pp(a, pp, s);
+      if (rc == 0 && a.split_k > 1) {
+        const long nthr = (long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+        return mvoc_check_launch("splitk_reduce_kernel");
+      }
+      return rc;
     }
   }
   // 3x3 / stride 1 / same-size convolutions: the tap-reuse kernel (no split-K form)

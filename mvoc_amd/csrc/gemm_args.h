@@ -1,0 +1,33 @@
+// Argument block shared by the implicit-GEMM kernel families (gemm.hip: per-tile blocks; gemm_pp.hip: the persistent
+// ping-pong kernel).
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+  const half_t* a;
+  const half_t* a2;
+  const half_t* w;
+  half_t* out;
+  const half_t* bias;
+  const half_t* rowadd;
+  const half_t* resid;
+  int M, N, K, n_store;
+  int ldo, ldr, ld_rowadd, rowadd_div;
+  int a_mode, lda, lda2, c1, cin;
+  int nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
+  float ups_sh, ups_sw;
+  int frames, hw;
+  int act;
+  int n_tiles, m_tiles;
+  const float* ln_s;   // LayerNorm folded into this GEMM: row sums of the gamma-scaled weights (fp32 [N]) or NULL
+  const float* ln_c;   //   beta @ W^T (+ bias), fp32 [N]
+  const float* ln_stats;  // optional precomputed {mean, rstd} per row (fp32 [M][2]); NULL: accumulated in the K loop
+  float ln_eps;
+  int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
+  float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
+  int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
+};
+
+
+// persistent ping-pong kernel (gemm_pp.hip): bn = 256 or 320 output channels per tile, 256 pixels per tile
+int mvoc_launch_gemm_pp(const GemmArgs& a, int bn, hipStream_t s);

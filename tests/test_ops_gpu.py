@@ -35,7 +35,7 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 91, 92])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
@@ -252,7 +252,7 @@ def test_tconv3(ops, frames, tile):
 # time-embedding row add and the residual.  Operands are small integers: every product and every fp32 partial sum is
 # exact and |result| < 2048 is exact in fp16, so the comparison with torch's CPU conv is BIT-EXACT -- any indexing slip in
 # a tile (tap order, source switch, swizzle, tail rows) shows as a wrong integer.
-PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67]
+PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 91, 92]
 _prod_cache = {}
 
 
@@ -295,6 +295,17 @@ def test_conv3x3_production_tiles_exact(ops, case, tile):
     out, _, _ = ops.conv3x3(c["x1"], pack_conv3x3(c["wt"]), c["b"], nimg=c["n"], h=c["h"], wd=c["w"], x2=c["x2"], rowadd=c["temb"],
                             rowadd_div=c["fr"] * c["h"] * c["w"], resid=c["res"], n_store=c["cout"], tile=tile, split_k=1)
     assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+
+
+@pytest.mark.parametrize("tile", [91, 92])
+@pytest.mark.parametrize("split_k", [2, 4])
+def test_pp_split_k_exact(ops, split_k, tile):
+    """persistent kernel with K slices as work units (fp32 slabs + the reduce pass)"""
+    from mvoc_amd.unet import pack_conv3x3
+    c, ref = _prod_case("conv1280+640_640")
+    out, _, _ = ops.conv3x3(c["x1"], pack_conv3x3(c["wt"]), c["b"], nimg=c["n"], h=c["h"], wd=c["w"], x2=c["x2"], rowadd=c["temb"],
+                            rowadd_div=c["fr"] * c["h"] * c["w"], resid=c["res"], n_store=c["cout"], split_k=split_k, tile=tile)
+    assert torch.equal(out.float().cpu(), ref)
 
 
 @pytest.mark.parametrize("split_k", [0, 2, 4, 8])
@@ -346,7 +357,7 @@ def test_linear_production_tiles_exact(ops, m, n, k, tile):
     assert torch.equal(out.float().cpu(), ref), f"tile {tile}"
 
 
-@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67])
+@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67, 91])
 @pytest.mark.parametrize("m,c,inner", [(16384, 320, 1280), (4096, 1280, 5120)])
 def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
     """GEGLU feed-forward entry with the LayerNorm folded in, at C = 320 (L0) and C = 1280 (L2) and production rows, on the

@@ -76,7 +76,9 @@ for key, (d, cnt) in rec.items():
             continue
         if tile in (2, 12, 14, 62, 64) and (d.act == 1 or d.n % 160):
             continue
-        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 61, 63, 65, 67):
+        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 61, 63, 65, 67, 91):
+            continue
+        if tile in (91, 92) and (d.m < 16384 or (tile == 92 and d.n % 320) or (tile == 91 and d.n % 256 and d.n < 1024)):
             continue
         try:
             for _ in range(2):
