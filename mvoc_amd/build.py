@@ -10,6 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvoc_hip.so")
 SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+LAB = os.environ.get("MVOC_BUILD_LAB") == "1"  # diagnostic library (in-kernel stamps / ablations): libmvoc_hip_lab.so
+if LAB:
+    LIB = os.path.join(HERE, "libmvoc_hip_lab.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"]
 # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified register file).  In AGPR form hipcc time-shares
@@ -38,8 +41,8 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", ".lab.o" if LAB else ".o"))
+        cmd = [HIPCC, *FLAGS, *(["-DMVOC_PP_LAB"] if LAB else []), *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -19,6 +19,8 @@
 //   reads are bank-conflict free (stride 20 dwords: 5r mod 16 is a bijection over a 16-lane group).
 // * 1-D grid with an XCD-aware remap: the n-tiles of one m-tile are neighbours on one XCD, so the activation
 //   tile they share is served by that XCD's L2.
+#include <stdlib.h>
+
 #include "gemm_args.h"
 
 namespace {
@@ -1117,13 +1119,20 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     const bool pp_ok = d->k % 32 == 0 && d->cin % 32 == 0 && d->c1 % 32 == 0 && a.epi_lds &&
                        (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin) && !(d->ln_rowsum && !d->ln_stats);
     int pp = 0;
-    if (d->tile == 91 || d->tile == 92) {
+    if (d->tile >= 91 && d->tile <= 94) {
       MVOC_REQUIRE(pp_ok && !(d->tile == 92 && d->act == MVOC_ACT_GEGLU), -2,
-                   "gemm: tiles 91 / 92 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
-      pp = d->tile == 91 ? 256 : 320;
+                   "gemm: tiles 91-94 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
+      pp = d->tile == 91 ? 256 : d->tile == 92 ? 320 : d->tile == 93 ? 2561 : 2562;  // 93 / 94: split LDS-DMA issue
     }
     if (pp) {
       a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
+#ifdef MVOC_PP_LAB
+      if (const char* e = getenv("MVOC_PP_LAB")) {  // "bits,stamp-buffer address" (diagnostic builds only)
+        unsigned long long ptr = 0;
+        sscanf(e, "%d,%llu", &a.lab, &ptr);
+        a.stamps = (unsigned long long*)ptr;
+      }
+#endif
       if (d->split_k > 1 && d->workspace && d->act != MVOC_ACT_GEGLU && !d->ln_rowsum && d->k % (32 * d->split_k) == 0 &&
           (size_t)d->split_k * d->m * d->n * 4 <= d->workspace_bytes) {
         a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;

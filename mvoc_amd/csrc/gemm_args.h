@@ -25,6 +25,8 @@ struct GemmArgs {
   float ln_eps;
   int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
   float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
+  int lab;                      // diagnostic builds only (MVOC_PP_LAB): bit 0 = no LDS-DMA in the K loop, bit 1 = all sources -> zero page
+  unsigned long long* stamps;   //   per-segment cycle sums of block 0 (waves 0 and 4): [2][8]
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 

@@ -39,7 +39,20 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TN, int NS>
+// In-kernel stamps (diagnostic instantiation only): s_memtime + its own lgkmcnt(0) as ONE statement, fenced for the scheduler
+#define PP_STAMP(t)                                                                            \
+  do {                                                                                         \
+    if constexpr (LAB) {                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");                 \
+      __builtin_amdgcn_sched_barrier(0);                                                       \
+    }                                                                                          \
+  } while (0)
+
+// SPLIT = how many of the wave's two activation pieces per stage are issued from inside its MFMA interval (between the 8th
+// and 9th MFMA) instead of its READ interval: a piece costs the issuing wave ~100 cycles, and four in a row made READ twice
+// as long as MFMA (in-kernel stamps, tools/pp_lab.py)
+template <int TN, int NS, bool LAB = false, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const int n_units) {
   constexpr int WM = 4, TM = 2;
   constexpr int BN = 2 * TN * 32, BM = WM * TM * 32;
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
       const bool ok = row < BN && n0 + row < p.N;
       wptr[i] = ok ? p.w + (size_t)(n0 + row) * p.K + cch + kbeg : zsrc;
       wstep[i] = ok ? KS : 0;
+      if (LAB && (p.lab & 2)) { wptr[i] = zsrc; wstep[i] = 0; }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -137,7 +151,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
     regather = true;
   };
 
-  auto issue = [&](int slot) {
+  bool need_setup = false;
+  auto issue_w = [&](int slot) {  // weight pieces of the next stage + (at a unit boundary) the new unit's row bookkeeping
+    if (need_setup) { setup_unit(p_unit); need_setup = false; }
     char* base = smem + slot * STAGE;
 #pragma unroll
     for (int i = 0; i < PWMAX; ++i) {
@@ -166,21 +182,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
         }
         aptr[i] = ok ? sbase + srow * ld + (cbase + cch) : zsrc;
         astep[i] = ok ? KS : 0;
+        if (LAB && (p.lab & 2)) { aptr[i] = zsrc; astep[i] = 0; }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
-                                       (__attribute__((address_space(3))) void*)(base + BN * ROWB + (wave + 8 * i) * 1024), 16, 0, 0);
-      aptr[i] += astep[i];
-    }
+  };
+  auto issue_a = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
+                                     (__attribute__((address_space(3))) void*)(smem + slot * STAGE + BN * ROWB + (wave + 8 * i) * 1024), 16, 0, 0);
+    aptr[i] += astep[i];
+  };
+  auto end_stage = [&]() {  // scalar bookkeeping only
     p_ch0 += KS;
     regather = p_ch0 == p.c1;
     if (p_ch0 >= p.cin) { p_ch0 = 0; ++p_tap; regather = true; }
     if (++p_kt == S) {
       p_kt = 0;
-      if (++p_unit < my_units) setup_unit(p_unit);
+      if (++p_unit < my_units) need_setup = true;
     }
+  };
+  auto issue = [&](int slot) {
+    issue_w(slot);
+    issue_a(slot, 0);
+    issue_a(slot, 1);
+    end_stage();
   };
 
   // counted waits: this wave issues P = npw + 2 pieces per stage
@@ -217,9 +241,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
 
   int c_unit = 0, c_kt = 0, slot = 0;
   bool skip_wait = false;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+  unsigned long long sum_rd = 0, sum_is = 0, sum_vw = 0, sum_b1 = 0, sum_mf = 0, sum_b2 = 0, sum_ep = 0, sum_all = 0;
+  const bool no_dma = LAB && (p.lab & 1);
+  (void)no_dma;
+  PP_STAMP(ts6);
+  const unsigned long long t_begin = ts6;
 #pragma unroll 1
   for (int g = 0; g < T; ++g) {
     // ================= READ(g) =================
+    PP_STAMP(ts0);
     half8_t wf[2][TN], af[2][TM];
     {
       const char* wl = smem + slot * STAGE + (wn * TN * 32 + r) * ROWB;
@@ -233,30 +264,61 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
         for (int j = 0; j < TM; ++j) af[s][j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROWB + off);
       }
     }
+    PP_STAMP(ts1);  // (diagnostic: the fragment reads are drained here)
     if (g + NS - 1 < T) {
       int fs = slot + NS - 1;
       if (fs >= NS) fs -= NS;
-      issue(fs);  // the slot stage g-1 lived in: both groups' reads of it were waited for before their last barrier
-      if (!skip_wait) wait_stages(NS - 2);  // stage g+1 of this wave's pieces has landed
-    } else if (!skip_wait) {
-      wait_stages(0);
+      // the slot stage g-1 lived in: both groups' reads of it were waited for before their last barrier
+      if (!no_dma) {
+        issue_w(fs);
+#pragma unroll
+        for (int i = 0; i < 2 - SPLIT; ++i) issue_a(fs, i);
+        if constexpr (SPLIT == 0) end_stage();
+      }
+      PP_STAMP(ts2);
+      if (!skip_wait) {  // stage g+1 of this wave's pieces has landed; SPLIT pieces of stage g+NS-1 are not issued yet
+        if constexpr (SPLIT == 0) wait_stages(NS - 2);
+        else { static_assert(SPLIT == 0 || (TN == 4 && NS == 4), "split issue: 256-wide tile"); wait_vm<8 - SPLIT>(); }
+      }
+    } else {
+      PP_STAMP(ts2);
+      if (!skip_wait) wait_stages(0);
     }
     skip_wait = false;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(ts3);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(ts4);
     // ================= MFMA(g) =================
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s][i], af[s][j], acc[i][j], 0, 0, 0);
+      if constexpr (SPLIT > 0) {
+        if (s == 0 && g + NS - 1 < T && !no_dma) {
+          int fs = slot + NS - 1;
+          if (fs >= NS) fs -= NS;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 2 - SPLIT; i < 2; ++i) issue_a(fs, i);
+          end_stage();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    PP_STAMP(ts5);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(ts6);
+    if constexpr (LAB) {
+      sum_rd += ts1 - ts0; sum_is += ts2 - ts1; sum_vw += ts3 - ts2; sum_b1 += ts4 - ts3; sum_mf += ts5 - ts4; sum_b2 += ts6 - ts5;
+    }
     slot = slot + 1 == NS ? 0 : slot + 1;
     if (++c_kt < S) continue;
     // ================= unit done: epilogue (no block barrier inside) =================
@@ -418,9 +480,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   }
   if (wn == 0) __builtin_amdgcn_s_barrier();  // group A's balancing barrier (B ran one extra at the start)
+  if constexpr (LAB) {
+    PP_STAMP(ts0);
+    sum_all = ts0 - t_begin;
+    sum_ep = sum_all - (sum_rd + sum_is + sum_vw + sum_b1 + sum_mf + sum_b2);
+    if (p.stamps && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {
+      unsigned long long* o = p.stamps + (wave >> 2) * 8;
+      o[0] = sum_rd; o[1] = sum_is; o[2] = sum_vw; o[3] = sum_b1; o[4] = sum_mf; o[5] = sum_b2; o[6] = sum_ep; o[7] = sum_all;
+    }
+  }
 }
 
-template <int TN, int NS>
+template <int TN, int NS, bool LAB = false, int SPLIT = 0>
 int launch_pp(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = 2 * TN * 32, BM = 256;
@@ -439,14 +510,19 @@ int launch_pp(const GemmArgs& a0, hipStream_t s) {
     ncu = v;
   }
   const int grid = (int)(units < ncu ? units : ncu);
-  hipLaunchKernelGGL((gemm_pp_kernel<TN, NS>), dim3((unsigned)grid), dim3(512), 0, s, a, (int)units);
+  hipLaunchKernelGGL((gemm_pp_kernel<TN, NS, LAB, SPLIT>), dim3((unsigned)grid), dim3(512), 0, s, a, (int)units);
   return mvoc_check_launch("gemm_pp_kernel");
 }
 
 }  // namespace
 
 int mvoc_launch_gemm_pp(const GemmArgs& a, int bn, hipStream_t s) {
+#ifdef MVOC_PP_LAB
+  if (bn == 256 && (a.lab || a.stamps)) return launch_pp<4, 4, true>(a, s);
+#endif
   if (bn == 256) return launch_pp<4, 4>(a, s);
+  if (bn == 2561) return launch_pp<4, 4, false, 1>(a, s);
+  if (bn == 2562) return launch_pp<4, 4, false, 2>(a, s);
   if (bn == 320) return launch_pp<5, 3>(a, s);
   mvoc_set_error("gemm_pp: unsupported tile width %d", bn);
   return -1;
