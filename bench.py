@@ -49,6 +49,9 @@ def parse():
                     help="diagnostic: the 3 source inversions of the job share one UNet call per step (batch 3, "
                          "I2VGenXLPipeline.invert_many) instead of three calls at batch 1; --steps must be a multiple of 4")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="longclip: frame<->pixel exchange form")
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="run under `rocprofv3 --pmc ...` (tools/pmc_bench.sh): eager launches, no priming, the K timed steps "
+                         "bracketed by two marker kernels so that the counter rows of exactly these steps can be cut out")
     return ap.parse_args()
 
 
@@ -233,18 +236,32 @@ def roofline_leg(job, steps):
     g = fam["gemm"]
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     total_ms = sum(v["ms"] for v in fam.values())
-    # HBM traffic of this kernel family comes from separate rocprofv3 --pmc passes (tools/pmc_bench.sh: FETCH_SIZE and
-    # WRITE_SIZE cannot share a pass; gfx950 FETCH_SIZE x2 correction applied); the committed summary is read back here
+    # HBM traffic of this kernel family: PMC counters cannot be read inside the timed process (FETCH_SIZE and WRITE_SIZE need
+    # separate rocprofv3 --pmc passes), so tools/pmc_bench.sh re-runs `bench.py --pmc-pass` (the same step mix, eager) per
+    # counter and cuts out the rows between the two marker kernels.  Its summary is used ONLY if it was taken with the
+    # library that is loaded now (digest of csrc) -- a stale summary reports null, not an old number.
     traffic, traffic_src = None, None
+    try:
+        digest = open(os.path.join(REPO, "mvoc_amd", "libmvoc_hip.so.stamp")).read().strip()
+    except OSError:
+        digest = None
+    cands = []
     for rnd in sorted(os.listdir(os.path.join(REPO, "profiles")), reverse=True):
         f = os.path.join(REPO, "profiles", rnd, "pmc_gemm_traffic.json")
         if os.path.exists(f):
-            traffic, traffic_src = json.load(open(f))["hbm_bytes_per_launch"], f"profiles/{rnd}/pmc_gemm_traffic.json"
+            cands.append((f, f"profiles/{rnd}/pmc_gemm_traffic.json"))
+    traffic_note = "no PMC summary committed for this build (tools/pmc_bench.sh)"
+    for f, rel in cands:
+        pj = json.load(open(f))
+        if digest is not None and pj.get("lib_digest") == digest and pj.get("mix") == "3 inversion : 1 composition":
+            traffic, traffic_src, traffic_note = pj["hbm_bytes_per_launch"], rel, pj.get("note")
             break
+        traffic_note = f"{rel} was taken with another build of the library: not reported"
     return {
         "bound": "mfma", "kernel": "gemm_kernel (implicit GEMM: linear / conv3x3 / temporal conv)",
         "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
-        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate run)", "traffic_source": traffic_src,
+        "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 --pmc passes over the same step mix)",
+        "traffic_source": traffic_src, "traffic_note": traffic_note,
         "algorithmic_bytes_per_launch_avg": round(alg_bytes[0] / max(g["launches"], 1)),
         "launches": int(g["launches"]), "avg_launch_us": round(1e3 * g["ms"] / max(g["launches"], 1), 2),
         "flops_per_launch_avg": g["work"] / max(g["launches"], 1),
@@ -261,15 +278,19 @@ def roofline_leg(job, steps):
 
 
 def cpu_baseline(frames, latent):
-    """the oracle (CPU restatement, fp32, PyTorch CPU ops) on a bounded sample, scaled to the bench step by FLOPs"""
-    from oracle import unet_ref as U
+    """the CPU restatement of the same path (oracle/: fp32 PyTorch CPU ops, the primitives diffusers
+    calls) timed on this node's host cores.  The bounded sample is BASELINE.json configs[0] IN FULL: one 8-frame 256x256
+    clip, 10-step DDIM inversion (UNet forward + inverse-DDIM update per step, oracle/loops_ref.invert_loop), 24.8 TFLOP;
+    ``value`` converts it to the metric's unit by FLOPs (one job-mix step of configs[1] = 41.9 TFLOP)."""
+    from oracle import loops_ref, sched_ref, unet_ref as U
     from mvoc_amd.flops import unet_flops
     from mvoc_amd.unet_spec import UNetConfig
-    # PyTorch CPU ops stop scaling (and regress badly) far below the 256 hardware threads of the GPU host on these
-    # op sizes: 32 threads is what is used and what `cores` reports
-    cores = min(os.cpu_count() or 1, 32)
+    # PyTorch CPU ops stop scaling (and regress) far below the hardware threads of the GPU host on these op sizes: 32
+    # threads is what is used and what `cores` reports; `host_cores` is what the node has
+    host = os.cpu_count() or 1
+    cores = min(host, 32)
     torch.set_num_threads(cores)
-    sample_hw = 32  # ~5 TFLOP per forward: three timed forwards are ~15 s of CPU work on 32 threads
+    f1, hw1, steps1 = 8, 32, 10
     cfg = UNetConfig()
     with torch.device("meta"):
         model = U.I2VGenXLUNet(U.UNetConfig())
@@ -279,23 +300,28 @@ def cpu_baseline(frames, latent):
         for p in model.parameters():
             n = p.numel()
             p.view(-1).copy_(noise.repeat((n + noise.numel() - 1) // noise.numel())[:n])
-        b, f = 1, frames
-        x = torch.randn(b, 4, f, sample_hw, sample_hw)
-        il = torch.randn(b, 4, f, sample_hw, sample_hw)
-        ie = torch.randn(b, 1, 1024)
-        eh = torch.randn(b, 77, 1024)
+        x = torch.randn(1, 4, f1, hw1, hw1).half()
+        il = torch.randn(1, 4, f1, hw1, hw1)
+        ie = torch.randn(1, 1, 1024)
+        eh = torch.randn(1, 77, 1024)
         fps = torch.tensor([8])
+
+        def unet_fn(inp, t):
+            return model(inp.float(), int(t), fps, il, ie, eh)[0].half()
+
         t0 = time.time()
-        for _ in range(3):
-            model(x, 981, fps, il, ie, eh)
-        dt = (time.time() - t0) / 3
-    fl_sample = unet_flops(cfg, 1, frames, sample_hw, sample_hw)["total"]
+        loops_ref.invert_loop(unet_fn, sched_ref.DDIMInverseSchedulerRef(), x, steps1, 1.0)
+        dt = time.time() - t0
+    fl_cfg1 = unet_flops(cfg, 1, f1, hw1, hw1)["total"]
     fl_step = (3 * unet_flops(cfg, 1, frames, latent, latent)["total"] + unet_flops(cfg, 5, frames, latent, latent)["total"]) / 4
+    cfg1_sps = steps1 / dt
     return {
-        "value": round((1.0 / dt) * fl_sample / fl_step, 6), "unit": "steps/s", "cores": cores, "kind": "port",
-        "sample": f"mean of 3 oracle UNet steps (oracle/unet_ref.py, fp32 PyTorch CPU ops) at B=1, F={frames}, {sample_hw}x{sample_hw} latents "
-                  f"= {fl_sample / 1e12:.2f} TFLOP in {dt:.1f} s; scaled by FLOPs to the job-mix step ({fl_step / 1e12:.2f} TFLOP)",
-        "sample_seconds": round(dt, 2),
+        "value": round(cfg1_sps * fl_cfg1 / fl_step, 6), "unit": "steps/s", "cores": cores, "host_cores": host, "kind": "port",
+        "sample": f"BASELINE configs[0] in full: {steps1}-step DDIM inversion of one {f1}-frame {hw1 * 8}x{hw1 * 8} clip on the oracle "
+                  f"(oracle/unet_ref.py + loops_ref.py, fp32 PyTorch CPU ops, {cores} threads) = {steps1 * fl_cfg1 / 1e12:.1f} TFLOP in "
+                  f"{dt:.1f} s = {cfg1_sps:.3f} cfg1-steps/s; scaled by FLOPs ({fl_cfg1 / 1e12:.2f} -> {fl_step / 1e12:.2f} TFLOP) to the "
+                  f"job-mix step",
+        "sample_seconds": round(dt, 2), "cfg1_steps_per_s": round(cfg1_sps, 4),
     }
 
 
@@ -392,8 +418,21 @@ def main():
 
     if args.workload == "longclip":
         return longclip(args, rank, world, device, dist)
+    if args.pmc_pass:
+        args.no_graphs = args.no_roofline = args.no_cpu_baseline = True
+        args.warmup = 0
     job = Job(device, args.frames, args.latent, not args.no_graphs)
     job.mix = args.mix
+    if args.pmc_pass:
+        from mvoc_amd import ops
+        torch.cuda.synchronize()
+        ops.delay_us(1)  # marker kernel (delay_kernel) in front of the timed steps
+        for k in range(args.steps):
+            job.step(k)
+        ops.delay_us(1)  # ... and behind them
+        torch.cuda.synchronize()
+        print(json.dumps({"pmc_pass": True, "steps": args.steps, "mix": "3 inversion : 1 composition"}), flush=True)
+        return
     if args.batch_inversions:
         if args.steps % 4 or args.mix != "job":
             raise SystemExit("--batch-inversions needs --mix job and --steps % 4 == 0 (one batched call = 3 inversion steps)")

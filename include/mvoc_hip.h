@@ -149,7 +149,8 @@ int mvoc_layernorm_f16(const void* x, const void* gamma, const void* beta, void*
  * PnP masked blend + scatter.  For every (frame f, pixel p, channel c):
  *     inj = base;  for j in objects:  inj = inj*(1-m_j) + obj_j*m_j     (three fp16-rounded ops, in this order)
  *     chunk[n-2] = chunk[n-1] = inj
- * with chunks positional [bg, obj_1..obj_k, uncond, cond] (k <= 4), base = chunk n-1 (or chunk 0 when
+ * with chunks positional [bg, obj_1..obj_k, uncond, cond] (k <= 4; the reference hard-codes k = 2, n = 5:
+ * pnp_utils.py:592,747,784,972,1061,1115), base = chunk n-1 (or chunk 0 when
  * base_chunk0 != 0), m_j = mask_j[f, nearest(p)] (fp16 values: exact {0,1} for bool masks, k/255 for soft masks).
  * BIT-EXACT against the reference arithmetic (not a select: -0.0 / inf / NaN propagate as in x*(1-m)+y*m).
  *   tokens: element (chunk, f, p, c) at x + chunk*chunk_stride + f*f_stride + p*p_stride + c   (c contiguous)
@@ -166,6 +167,8 @@ typedef struct mvoc_pnp_desc {
   const void* masks;
   int64_t chunk_stride, f_stride, p_stride;
   int32_t nobj, frames, height, width, channels, mask_h, mask_w, base_chunk0;
+  int32_t ndst;  /* trailing destination chunks: 0 or 2 = [uncond, cond] (the reference's layout), 1 = [cond] only: the
+                    classifier-free-guidance-off batch [bg, obj_1..obj_k, cond] (n = k + 2) */
 } mvoc_pnp_desc;
 int mvoc_pnp_blend_scatter_tokens(const mvoc_pnp_desc* d, void* stream);
 int mvoc_pnp_blend_scatter_nchw(const mvoc_pnp_desc* d, void* stream);

@@ -54,7 +54,7 @@ class GnDesc(C.Structure):
 class PnpDesc(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("masks", vp), ("chunk_stride", i64), ("f_stride", i64), ("p_stride", i64),
                 ("nobj", i32), ("frames", i32), ("height", i32), ("width", i32), ("channels", i32), ("mask_h", i32),
-                ("mask_w", i32), ("base_chunk0", i32)]
+                ("mask_w", i32), ("base_chunk0", i32), ("ndst", i32)]
 
 
 # every symbol include/mvoc_hip.h declares: name -> (restype, argtypes)

@@ -15,6 +15,7 @@ struct PnpArgs {
   const half_t* masks;
   long chunk_stride, f_stride, p_stride;
   int nobj, frames, height, width, channels, mask_h, mask_w, base_chunk0;
+  int ndst;      // trailing destination chunks: 2 = [uncond, cond] (the reference's CFG layout), 1 = [cond] (CFG off)
   float sy, sx;  // nearest-resize scales mask_h/height, mask_w/width (as F.interpolate computes them)
   long total;    // work items per tensor
 };
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void pnp_tokens_kernel(const PnpArgs p) {
   const int py = px / p.width, pxx = px - py * p.width;
   const int my = nearest_src(py, p.sy, p.mask_h), mx = nearest_src(pxx, p.sx, p.mask_w);
   const long off = (long)f * p.f_stride + (long)px * p.p_stride + c8 * 8;
-  const int nchunk = p.nobj + 3;
+  const int nchunk = p.nobj + 1 + p.ndst;
   const int basec = p.base_chunk0 ? 0 : nchunk - 1;
   const half8_t bv = *reinterpret_cast<const half8_t*>(x + basec * p.chunk_stride + off);
   float inj[8];
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void pnp_tokens_kernel(const PnpArgs p) {
   half8_t o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (half_t)inj[e];
-  *reinterpret_cast<half8_t*>(x + (nchunk - 2) * p.chunk_stride + off) = o;
+  if (p.ndst == 2) *reinterpret_cast<half8_t*>(x + (nchunk - 2) * p.chunk_stride + off) = o;
   *reinterpret_cast<half8_t*>(x + (nchunk - 1) * p.chunk_stride + off) = o;
 }
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void pnp_nchw_kernel(const PnpArgs p) {
   const int f = (int)(fc / p.channels);
   const long off = fc * hw + (long)pv * VEC;  // (f*C + c)*HW + p
   const long chunk = (long)p.frames * p.channels * hw;
-  const int nchunk = p.nobj + 3;
+  const int nchunk = p.nobj + 1 + p.ndst;
   const int basec = p.base_chunk0 ? 0 : nchunk - 1;
   float inj[VEC];
   half_t tmp[VEC];
@@ -102,10 +103,10 @@ __global__ __launch_bounds__(256) void pnp_nchw_kernel(const PnpArgs p) {
 #pragma unroll
   for (int e = 0; e < VEC; ++e) tmp[e] = (half_t)inj[e];
   if constexpr (VEC == 8) {
-    *reinterpret_cast<half8_t*>(x + (nchunk - 2) * chunk + off) = *reinterpret_cast<half8_t*>(tmp);
+    if (p.ndst == 2) *reinterpret_cast<half8_t*>(x + (nchunk - 2) * chunk + off) = *reinterpret_cast<half8_t*>(tmp);
     *reinterpret_cast<half8_t*>(x + (nchunk - 1) * chunk + off) = *reinterpret_cast<half8_t*>(tmp);
   } else {
-    x[(nchunk - 2) * chunk + off] = tmp[0];
+    if (p.ndst == 2) x[(nchunk - 2) * chunk + off] = tmp[0];
     x[(nchunk - 1) * chunk + off] = tmp[0];
   }
 }
@@ -121,6 +122,8 @@ int fill_args(const mvoc_pnp_desc* d, PnpArgs& a) {
   a.chunk_stride = d->chunk_stride; a.f_stride = d->f_stride; a.p_stride = d->p_stride;
   a.nobj = d->nobj; a.frames = d->frames; a.height = d->height; a.width = d->width; a.channels = d->channels;
   a.mask_h = d->mask_h; a.mask_w = d->mask_w; a.base_chunk0 = d->base_chunk0;
+  MVOC_REQUIRE(d->ndst >= 0 && d->ndst <= 2, -1, "pnp: ndst %d not in {0 (= 2), 1, 2}", d->ndst);
+  a.ndst = d->ndst == 0 ? 2 : d->ndst;
   a.sy = (float)d->mask_h / (float)d->height;
   a.sx = (float)d->mask_w / (float)d->width;
   return 0;
@@ -186,7 +189,7 @@ extern "C" int mvoc_pnp_blend_scatter_tokens(const mvoc_pnp_desc* d, void* strea
   const int ntens = d->x2 ? 2 : 1;
   hipStream_t s = (hipStream_t)stream;
   const double elems = (double)d->frames * d->height * d->width * d->channels;
-  MvocProfScope prof(MVOC_FAM_PNP, s, ntens * (elems * 2.0 * (d->nobj + 3) + 2.0 * d->nobj * d->frames * d->height * d->width));
+  MvocProfScope prof(MVOC_FAM_PNP, s, ntens * (elems * 2.0 * (d->nobj + 1 + a.ndst) + 2.0 * d->nobj * d->frames * d->height * d->width));
   hipLaunchKernelGGL(pnp_tokens_kernel, dim3((unsigned)nblk, ntens), dim3(256), 0, s, a);
   return mvoc_check_launch("pnp_tokens_kernel");
 }
@@ -202,7 +205,7 @@ extern "C" int mvoc_pnp_blend_scatter_nchw(const mvoc_pnp_desc* d, void* stream)
   const int ntens = d->x2 ? 2 : 1;
   hipStream_t s = (hipStream_t)stream;
   const double elems = (double)d->frames * hw * d->channels;
-  MvocProfScope prof(MVOC_FAM_PNP, s, ntens * (elems * 2.0 * (d->nobj + 3) + 2.0 * d->nobj * d->frames * hw));
+  MvocProfScope prof(MVOC_FAM_PNP, s, ntens * (elems * 2.0 * (d->nobj + 1 + a.ndst) + 2.0 * d->nobj * d->frames * hw));
   if (vec)
     hipLaunchKernelGGL(pnp_nchw_kernel<8>, dim3((unsigned)nblk, ntens), dim3(256), 0, s, a);
   else

@@ -247,7 +247,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
-def _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0):
+def _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0, ndst=2):
     _chk(x, "x"), _chk(x2, "x2"), _chk(masks, "masks")
     if masks.dim() != 4 or not masks.is_contiguous() or masks.shape[1] != frames:
         raise RuntimeError(f"pnp: masks must be contiguous [nobj, F, mh, mw] fp16, got {tuple(masks.shape)}")
@@ -255,23 +255,24 @@ def _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, wi
     d.x, d.x2, d.masks = x.data_ptr(), _ptr(x2), masks.data_ptr()
     d.chunk_stride, d.f_stride, d.p_stride = chunk_stride, f_stride, p_stride
     d.nobj, d.frames, d.height, d.width, d.channels = masks.shape[0], frames, height, width, channels
-    d.mask_h, d.mask_w, d.base_chunk0 = masks.shape[2], masks.shape[3], int(base_chunk0)
+    d.mask_h, d.mask_w, d.base_chunk0, d.ndst = masks.shape[2], masks.shape[3], int(base_chunk0), int(ndst)
     return d
 
 
 def pnp_blend_tokens(x, masks, *, frames, height, width, channels, chunk_stride, f_stride, p_stride, x2=None,
-                     base_chunk0=False):
-    """In-place masked blend + scatter on channel-contiguous data (see include/mvoc_hip.h)."""
-    d = _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0)
+                     base_chunk0=False, ndst=2):
+    """In-place masked blend + scatter on channel-contiguous data (see include/mvoc_hip.h).  ``ndst``: trailing
+    destination chunks (2 = [uncond, cond], 1 = [cond] with CFG off)."""
+    d = _pnp_desc(x, x2, masks, chunk_stride, f_stride, p_stride, frames, height, width, channels, base_chunk0, ndst)
     check(lib.mvoc_pnp_blend_scatter_tokens(C.byref(d), _stream()), "pnp_blend_scatter_tokens")
     return x
 
 
-def pnp_blend_nchw(x, masks, *, frames, x2=None, base_chunk0=True):
-    """In-place on x [(nobj+3)*F, C, H, W] (reference feature-map layout)."""
+def pnp_blend_nchw(x, masks, *, frames, x2=None, base_chunk0=True, ndst=2):
+    """In-place on x [(nobj+1+ndst)*F, C, H, W] (reference feature-map layout)."""
     if x.dim() != 4 or not x.is_contiguous():
         raise RuntimeError("pnp_blend_nchw: x must be contiguous [N, C, H, W]")
-    d = _pnp_desc(x, x2, masks, 0, 0, 0, frames, x.shape[2], x.shape[3], x.shape[1], base_chunk0)
+    d = _pnp_desc(x, x2, masks, 0, 0, 0, frames, x.shape[2], x.shape[3], x.shape[1], base_chunk0, ndst)
     check(lib.mvoc_pnp_blend_scatter_nchw(C.byref(d), _stream()), "pnp_blend_scatter_nchw")
     return x
 

@@ -342,7 +342,8 @@ class I2VGenXLPipeline:
         """static buffers + the captured iteration variants of the composition loop.
         cond: dict(encoder_hidden_states [n,77,D], image_embeddings [n,F,D], image_latents_first, image_latents, fps)"""
         n_obj = len(masks)
-        nb = n_obj + 3
+        do_cfg = guidance_scale > 1  # off: batch [bg, objs.., cond], one destination chunk for the injections (SURVEY 8f-4)
+        nb = n_obj + (3 if do_cfg else 2)
         dev = self.device
         st = {"latents": latents.clone(), "inp": torch.empty((nb,) + tuple(latents.shape[1:]), dtype=H16, device=dev),
               "t": torch.zeros(1, dtype=torch.float32, device=dev), "coef": torch.zeros(5, dtype=torch.float32, device=dev),
@@ -356,20 +357,22 @@ class I2VGenXLPipeline:
 
         def body():
             x = st["latents"]
-            st["inp"][nb - 2].copy_(x[0])
+            if do_cfg:
+                st["inp"][nb - 2].copy_(x[0])
             st["inp"][nb - 1].copy_(x[0])
             noise = self.unet.forward_ext(st["inp"], st["t"], cond["fps"], cond["image_latents_first"], cond["image_latents"],
                                           cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False,
                                           conditioning=prepared)[0]
-            ops.ddim_step(x, noise[nb - 1:nb].contiguous(), st["coef"], v_uncond=noise[nb - 2:nb - 1].contiguous(), out=x)
+            ops.ddim_step(x, noise[nb - 1:nb].contiguous(), st["coef"],
+                          v_uncond=noise[nb - 2:nb - 1].contiguous() if do_cfg else None, out=x)
 
         st["body"] = body
+        st["nb"] = nb
         return st
 
     def composition_step(self, st, t, bg_latents, obj_latents, table_row, fuse=None):
         """one iteration of ``:1636-1734`` on device-resident latents; ``fuse`` = (mix_ratio, obj_random_noise_fusion,
         fusion object latents) on fusion steps"""
-        nb = st["n_obj"] + 3
         if fuse is not None:
             mix, rnf, fobjs = fuse
             for j, o in enumerate(fobjs):
@@ -408,30 +411,32 @@ class I2VGenXLPipeline:
         or pass ``obj_masks_tensors`` = list of (float [1,4,F,h,w], bool [1,4,F,h,w]) directly."""
         from .utils import mask_preprocess
         self._guidance_scale = guidance_scale
-        if guidance_scale <= 1:
-            raise NotImplementedError("the reference's hooks hard-code the CFG batch layout [bg, objs.., uncond, cond]")
+        # guidance_scale <= 1: classifier-free guidance off.  The reference's hooks hard-code the batch of 5
+        # (pnp_utils.py:592,747,784,972,1061,1115: `// 5`) and cannot run this; here the batch is [bg, objs.., cond], the
+        # injections write the single trailing chunk and the DDIM update takes the conditional prediction as it is
+        do_cfg = guidance_scale > 1
         c = self.conditioner
         n_obj = len(obj_ddim_latents_path)
         assert obj_mask is None or len(obj_mask) == n_obj
         # conditioning, assembled in the reference's batch order [bg, obj_1.., uncond, cond] (:1387, 1476, 1498, 1540)
         pe, ne = (prompt_embeds, negative_prompt_embeds) if prompt_embeds is not None else c.encode_prompt(prompt, negative_prompt)
         inv_pe, _ = c.encode_prompt(ddim_inv_prompt, negative_prompt)
-        ehs = torch.cat([inv_pe.repeat(n_obj + 1, 1, 1), ne, pe])
+        ehs = torch.cat([inv_pe.repeat(n_obj + 1, 1, 1)] + ([ne] if do_cfg else []) + [pe])
         main_lat = c.image_latents(main_first_image, num_frames, height, width)
         bg_lat = c.image_latents(background_first_image, num_frames, height, width)
         obj_first = [c.image_latents(im, num_frames, height, width) for im in objs_first_image]
-        first_all = torch.cat([bg_lat] + obj_first + [main_lat, main_lat])
+        first_all = torch.cat([bg_lat] + obj_first + [main_lat] * (2 if do_cfg else 1))
         obj_lat = [c.image_latents(frames[0], num_frames, height, width) for frames in objs_image_list]
         bg_lat2 = c.image_latents(background_image_list[0], num_frames, height, width)
-        lat_all = torch.cat([bg_lat2] + obj_lat + [main_lat, main_lat])
+        lat_all = torch.cat([bg_lat2] + obj_lat + [main_lat] * (2 if do_cfg else 1))
 
         def emb_list(frames):
             return torch.cat([c.encode_image(f) for f in frames], dim=1)
 
         main_emb = emb_list(main_image_list)
         emb_all = torch.cat([emb_list(background_image_list)] + [emb_list(fr) for fr in objs_image_list]
-                            + [torch.zeros_like(main_emb), main_emb])
-        fps = torch.full((n_obj + 3,), float(target_fps), dtype=torch.float32, device=self.device)
+                            + ([torch.zeros_like(main_emb)] if do_cfg else []) + [main_emb])
+        fps = torch.full((n_obj + (3 if do_cfg else 2),), float(target_fps), dtype=torch.float32, device=self.device)
         cond = dict(encoder_hidden_states=ehs.to(self.device, H16).contiguous(), image_embeddings=emb_all.to(self.device, H16).contiguous(),
                     image_latents_first=first_all.to(self.device, H16).contiguous(), image_latents=lat_all.to(self.device, H16).contiguous(), fps=fps)
 

@@ -197,11 +197,11 @@ class Transformer2DModel(_TransformerBase):
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         proc = blk.attn1.processor
         if proc.injecting():
-            eng.check_pnp_batch(B, proc.mask)
+            ndst = eng.check_pnp_batch(B, proc.mask)
             masks = eng.device_masks(proc.mask)[1]  # bool masks as {0,1} fp16
             ld = qkv.stride(0)
             ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
-                                 f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
+                                 f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background, ndst=ndst)
         a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
         h = blk.attn1.to_out(a, resid=h)
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
@@ -243,11 +243,11 @@ class TransformerTemporalModel(_TransformerBase):
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
             proc = attn.processor
             if attn is blk.attn1 and proc.injecting():
-                eng.check_pnp_batch(B, proc.mask)
+                ndst = eng.check_pnp_batch(B, proc.mask)
                 masks = eng.section_masks(proc.mask, 0, full_hw)  # soft float masks, channel 0
                 ld = qkv.stride(0)
                 ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
-                                     f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background)
+                                     f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background, ndst=ndst)
             a = ops.temporal_attn(q, k, v, nsample=B, frames=F, hw=hw, heads=self.heads)
             h = attn.to_out(a, resid=h)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
@@ -524,11 +524,15 @@ class I2VGenXLUNet:
     # ---- PnP helpers ------------------------------------------------------------------------------
     @staticmethod
     def check_pnp_batch(B, mask_list):
-        """the hooks address chunks positionally [bg, obj_1..obj_n, uncond, cond] (pnp_utils.py:592 hard-codes 5)"""
-        if mask_list is None or B != len(mask_list) + 3:
+        """the hooks address chunks positionally [bg, obj_1..obj_n, uncond, cond] (pnp_utils.py:592 hard-codes 5); with
+        classifier-free guidance off the batch is [bg, obj_1..obj_n, cond].  Returns the number of
+        trailing destination chunks (2 or 1)."""
+        if mask_list is None or B - len(mask_list) - 1 not in (1, 2):
             raise RuntimeError(f"PnP injection is active but the UNet batch is {B}, expected n_objects+3 = "
-                               f"{None if mask_list is None else len(mask_list) + 3} ([bg, objects.., uncond, cond]); "
+                               f"{None if mask_list is None else len(mask_list) + 3} ([bg, objects.., uncond, cond]) or "
+                               "n_objects+2 with guidance off; "
                                "clear the hook state (register_time_all(pipe, None, None)) before non-composition calls")
+        return B - len(mask_list) - 1
 
     def device_masks(self, mask_list):
         """list of (float [1,4,F,h,w], bool [1,4,F,h,w]) pairs (``register_time_all``'s ``mask``) ->
@@ -589,7 +593,7 @@ class I2VGenXLUNet:
         """feature injection (``pnp_utils.py:970-1004, 1059-1082, 1114-1146``): base = chunk 0, bool mask, no resize.
         ``full_hw`` is given by temporal sections (see ``section_masks``); elsewhere the rows are whole local frames."""
         B, F, H, W = geo
-        self.check_pnp_batch(B, mask_list)
+        ndst = self.check_pnp_batch(B, mask_list)
         hard = self._all_frame_masks(mask_list)[1]
         fh, fw = full_hw if full_hw is not None else (H, W)
         if hard.shape[2] != fh or hard.shape[3] != fw:
@@ -598,7 +602,7 @@ class I2VGenXLUNet:
         hard = self.section_masks(mask_list, 1, full_hw) if full_hw is not None else self.device_masks(mask_list)[1]
         ld = h.stride(0)
         ops.pnp_blend_tokens(h, hard, frames=F, height=H, width=W, channels=channels, chunk_stride=F * H * W * ld,
-                             f_stride=H * W * ld, p_stride=ld, base_chunk0=True)
+                             f_stride=H * W * ld, p_stride=ld, base_chunk0=True, ndst=ndst)
 
     # ---- frame-axis shard plumbing --------------------------------------------------------------------
     def temporal_section(self, x, geo, section):
@@ -806,12 +810,12 @@ class I2VGenXLUNet:
         co = self.conv_out
         y, _, _ = ops.conv3x3(h, co.w, co.b, nimg=B * F, h=H, wd=W, n_store=co.cout)
         if co.injecting():
-            self.check_pnp_batch(B, co.mask)
+            ndst = self.check_pnp_batch(B, co.mask)
             # conv_out writes cout (4) channels into a [rows, 4] buffer: the token kernel needs channels % 8 == 0,
             # so this tiny tensor goes through the NCHW form of the kernel on the boundary layout instead
             out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)  # [B,C,F,h,w]
             nchw = out.permute(0, 2, 1, 3, 4).reshape(B * F, co.cout, H, W).contiguous()
-            ops.pnp_blend_nchw(nchw, self.device_masks(co.mask)[1], frames=F, base_chunk0=True)
+            ops.pnp_blend_nchw(nchw, self.device_masks(co.mask)[1], frames=F, base_chunk0=True, ndst=ndst)
             out = nchw.reshape(B, F, co.cout, H, W).permute(0, 2, 1, 3, 4).contiguous()
         else:
             out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)

@@ -90,8 +90,10 @@ def composition_loop(unet_fn, scheduler, latents, bg_latents_at, obj_latents_at,
 
     ``bg_latents_at(t)`` / ``obj_latents_at(j, t)`` return ``[1,4,F,h,w]`` latents at noise level t (the
     ``ddim_latents_{t}.pt`` files).  ``unet_fn(x[5,4,F,h,w], t) -> [5,4,F,h,w]``; ``on_step(i, t)`` is the
-    ``register_time_all`` hook point.  Returns final latents."""
+    ``register_time_all`` hook point.  Returns final latents.  ``guidance_scale <= 1``: the CFG-off generalisation
+    (not runnable in the reference): batch ``[bg, objs.., cond]``, no CFG combine."""
     n_obj = len(float_masks)
+    do_cfg = guidance_scale > 1.0
     offs = obj_ddim_latents_idx_offset or [0] * n_obj
     scheduler.set_timesteps(n_steps)
     full_ts = scheduler.timesteps.clone()
@@ -105,11 +107,11 @@ def composition_loop(unet_fn, scheduler, latents, bg_latents_at, obj_latents_at,
             latents = latent_fusion(latents, bg, objs, float_masks, random_noise_ratio, obj_random_noise_fusion)
         else:
             objs = [obj_latents_at(j, int(t)) for j in range(n_obj)]
-        inp = torch.cat([bg] + objs + [latents, latents])
+        inp = torch.cat([bg] + objs + [latents] * (2 if do_cfg else 1))
         if on_step is not None:
             on_step(i, int(t))
         noise_pred = unet_fn(inp, t)
-        chunks = noise_pred.chunk(n_obj + 3)
-        noise_pred = cfg_combine(chunks[-2], chunks[-1], guidance_scale)
+        chunks = noise_pred.chunk(n_obj + (3 if do_cfg else 2))
+        noise_pred = cfg_combine(chunks[-2], chunks[-1], guidance_scale) if do_cfg else chunks[-1]
         latents = scheduler_step_5d(scheduler, noise_pred, t, latents)
     return latents

@@ -24,6 +24,7 @@ class PnPState:
         self.inject_background = inject_background
         self.t = None
         self.masks = None  # list of (float [1,4,F,h,w], bool [1,4,F,h,w])
+        self.ndst = 2      # trailing destination chunks: 2 = [uncond, cond] (reference), 1 = CFG off (generalisation)
 
     @staticmethod
     def _on(schedule, t):
@@ -52,10 +53,10 @@ class _PnPProcessor:
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         k, v = attn.to_k(ctx), attn.to_v(ctx)
         if self.temporal and st.temporal_on():
-            q, k = pnp_ref.inject_qk_temporal(q, k, [m[0] for m in st.masks], height, width, st.inject_background)
+            q, k = pnp_ref.inject_qk_temporal(q, k, [m[0] for m in st.masks], height, width, st.inject_background, st.ndst)
         elif (not self.temporal) and st.spatial_on():
-            nf = b // (len(st.masks) + 3)
-            q, k = pnp_ref.inject_qk_spatial(q, k, [m[1] for m in st.masks], nf, height, width, st.inject_background)
+            nf = b // (len(st.masks) + 1 + st.ndst)
+            q, k = pnp_ref.inject_qk_spatial(q, k, [m[1] for m in st.masks], nf, height, width, st.inject_background, st.ndst)
         hd = k.shape[-1] // attn.heads
         q = q.view(b, -1, attn.heads, hd).transpose(1, 2)
         k = k.view(b, -1, attn.heads, hd).transpose(1, 2)
@@ -77,7 +78,7 @@ def install_pnp(unet, state: PnPState):
             h = h + rn.time_emb_proj(rn.nonlinearity(temb))[:, :, None, None]
             h = rn.conv2(rn.nonlinearity(rn.norm2(h)))
             if state.conv_on():
-                h = pnp_ref.inject_feature_nchw(h, [m[1] for m in state.masks])
+                h = pnp_ref.inject_feature_nchw(h, [m[1] for m in state.masks], state.ndst)
             if rn.conv_shortcut is not None:
                 input_tensor = rn.conv_shortcut(input_tensor)
             return (input_tensor + h) / rn.output_scale_factor
@@ -87,7 +88,7 @@ def install_pnp(unet, state: PnPState):
         def forward(hidden_states, num_frames=1):
             y = orig(hidden_states, num_frames=num_frames)
             if state.conv_on():
-                y = pnp_ref.inject_feature_nchw(y, [m[1] for m in state.masks])
+                y = pnp_ref.inject_feature_nchw(y, [m[1] for m in state.masks], state.ndst)
             return y
         return forward
 
@@ -95,7 +96,7 @@ def install_pnp(unet, state: PnPState):
         def forward(x):
             y = orig(x)
             if state.conv_on():
-                y = pnp_ref.inject_feature_nchw(y, [m[1] for m in state.masks])
+                y = pnp_ref.inject_feature_nchw(y, [m[1] for m in state.masks], state.ndst)
             return y
         return forward
 

@@ -662,6 +662,43 @@ def test_pnp_tokens_n_objects_bit_exact(ops, nobj, bg):
     assert torch.equal(bits(dx), bits(ref))
 
 
+@pytest.mark.parametrize("nobj", [1, 2, 4])
+@pytest.mark.parametrize("bg", [False, True])
+def test_pnp_cfg_off_layout_bit_exact(ops, nobj, bg):
+    """classifier-free guidance OFF -- batch [bg, obj_1..obj_n, cond], ONE destination chunk (``ndst=1``).
+    Spatial tokens (bool masks), temporal layout (soft masks) and the NCHW feature form, bit for bit against the oracle's
+    generalisation (the reference hard-codes `// 5` and cannot run this layout)"""
+    from oracle import pnp_ref
+    g = torch.Generator().manual_seed(60 + nobj)
+    Fr, H, W, C, nb = 3, 6, 5, 64, nobj + 2
+    q = torch.randn(nb * Fr, H * W, C, generator=g).half()
+    k = torch.randn(nb * Fr, H * W, C, generator=g).half()
+    q[1, 0, :4] = torch.tensor([float("inf"), -0.0, float("nan"), 65504.0]).half()
+    hard = torch.rand(nobj, Fr, 12, 10, generator=g) > 0.5
+    rq, rk = pnp_ref.inject_qk_spatial(q, k, [hard[j] for j in range(nobj)], Fr, H, W, inject_background=bg, ndst=1)
+    dq, dk = dev(q), dev(k)
+    ops.pnp_blend_tokens(dq, dev(hard.half()), x2=dk, frames=Fr, height=H, width=W, channels=C, chunk_stride=Fr * H * W * C,
+                         f_stride=H * W * C, p_stride=C, base_chunk0=bg, ndst=1)
+    assert torch.equal(bits(dq), bits(rq)) and torch.equal(bits(dk), bits(rk))
+    assert torch.equal(bits(dq[:(nb - 1) * Fr]), bits(q[:(nb - 1) * Fr]))  # sources untouched: only the last chunk is written
+    # temporal layout [nb*HW, F, C], soft masks k/255
+    qt = torch.randn(nb * H * W, Fr, C, generator=g).half()
+    kt = torch.randn(nb * H * W, Fr, C, generator=g).half()
+    soft = (torch.randint(0, 256, (nobj, Fr, 9, 7), generator=g).float() / 255).half()
+    rqt, rkt = pnp_ref.inject_qk_temporal(qt, kt, [soft[j] for j in range(nobj)], H, W, inject_background=bg, ndst=1)
+    dqt, dkt = dev(qt), dev(kt)
+    ops.pnp_blend_tokens(dqt, dev(soft), x2=dkt, frames=Fr, height=H, width=W, channels=C, chunk_stride=H * W * Fr * C,
+                         f_stride=C, p_stride=Fr * C, base_chunk0=bg, ndst=1)
+    assert torch.equal(bits(dqt), bits(rqt)) and torch.equal(bits(dkt), bits(rkt))
+    # feature form
+    x = torch.randn(nb * Fr, 24, H, W, generator=g).half()
+    hard2 = torch.rand(nobj, Fr, H, W, generator=g) > 0.5
+    ref = pnp_ref.inject_feature_nchw(x, [hard2[j] for j in range(nobj)], ndst=1)
+    dx = dev(x)
+    ops.pnp_blend_nchw(dx, dev(hard2.half()), frames=Fr, base_chunk0=True, ndst=1)
+    assert torch.equal(bits(dx), bits(ref))
+
+
 @pytest.mark.parametrize("tile", [111, 112, 164, 166])
 @pytest.mark.parametrize("shape", [(3, 64, 320, 9, 7), (2, 128, 320, 16, 16), (5, 64, 640, 5, 33), (1, 64, 160, 3, 3), (2, 192, 320, 40, 8)])
 def test_conv3x3_tap_reuse(ops, tile, shape):

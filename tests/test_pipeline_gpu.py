@@ -567,3 +567,88 @@ def test_longclip_workload_at_cfg4_size():
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["config"]["frames"] == 32 and j["config"]["height"] == 768 and j["n_gpus"] == 1 and j["value"] > 0
     print("longclip 32x768x768, 1 GPU:", j["ms_per_step"], "ms/step")
+
+
+def test_composition_cfg_off_vs_oracle():
+    """composition with classifier-free guidance OFF (guidance_scale 1.0): UNet batch [bg, obj1, obj2, cond],
+    every injection family writes the single trailing chunk, the DDIM update takes the conditional prediction -- against the
+    oracle's generalisation of the loop and of the hooks (the reference raises on this layout: `// 5` is hard-coded)"""
+    from oracle import loops_ref, sched_ref
+    from oracle.pnp_model_ref import PnPState, install_pnp
+    from mvoc_amd import pnp_utils
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMScheduler
+    o, eng = _pair()
+    g = torch.Generator().manual_seed(15)
+    f, h, w, cd, n = 3, 8, 8, 64, 4
+    r = lambda *s_: torch.randn(*s_, generator=g).half()
+    cond = dict(encoder_hidden_states=r(4, 7, cd), image_embeddings=r(4, f, cd), image_latents_first=r(4, 4, f, h, w),
+                image_latents=r(4, 4, f, h, w))
+    cond["encoder_hidden_states"][1] = cond["encoder_hidden_states"][0]
+    cond["encoder_hidden_states"][2] = cond["encoder_hidden_states"][0]
+    cond["image_latents"][3] = cond["image_latents_first"][3]
+    u8 = torch.randint(0, 256, (2, f, h, w), generator=g)
+    masks = [((u8[j].float() / 255).half()[None, None].repeat(1, 4, 1, 1, 1), (u8[j] > 10)[None, None].repeat(1, 4, 1, 1, 1)) for j in range(2)]
+    s = DDIMScheduler()
+    s.set_timesteps(n)
+    src = {(k, int(t)): r(1, 4, f, h, w) for k in range(3) for t in s.timesteps}
+    x0 = r(1, 4, f, h, w)
+    rs = sched_ref.DDIMSchedulerRef()
+    rs.set_timesteps(n)
+    st = PnPState(conv_schedule=rs.timesteps[:2], spatial_schedule=rs.timesteps[:3], temporal_schedule=rs.timesteps[:4])
+    st.ndst = 1
+    install_pnp(o, st)
+    st.masks = masks
+
+    def unet_fn(inp, t):
+        st.t = int(t)
+        assert inp.shape[0] == 4
+        return o.forward_ext(inp.float(), int(t), torch.tensor([8] * 4), cond["image_latents_first"].float(), cond["image_latents"].float(),
+                             cond["image_embeddings"].float(), cond["encoder_hidden_states"].float())[0].half()
+
+    ref = loops_ref.composition_loop(unet_fn, sched_ref.DDIMSchedulerRef(), x0, lambda t: src[(0, t)], lambda j, t: src[(1 + j, t)],
+                                     [m[0] for m in masks], n, guidance_scale=1.0, ddim_init_latents_t_idx=0, fusion_steps=(0, 1),
+                                     random_noise_ratio=0.0)
+    results = []
+    for graphs in (False, True):
+        pipe = I2VGenXLPipeline(eng, DDIMScheduler(), use_graphs=graphs)
+        pnp_utils.register_temp_attention_pnp(pipe, s.timesteps[:4], False)
+        pnp_utils.register_spatial_attention_pnp(pipe, s.timesteps[:3], False)
+        pnp_utils.register_temp_conv_injection(pipe, s.timesteps[:2])
+        pnp_utils.register_out_conv_injection(pipe, s.timesteps[:2])
+        pnp_utils.register_resnet_injection(pipe, s.timesteps[:2])
+        for (k, t), v in src.items():
+            pipe.latent_cache.put(f"/virtual/src{k}", t, v.cuda())
+        pipe.latent_cache.write_files = False
+
+        class Cond:
+            def encode_prompt(self, prompt, negative_prompt=None):
+                if prompt == "edit":
+                    return cond["encoder_hidden_states"][3:4].cuda(), cond["encoder_hidden_states"][3:4].cuda()
+                return cond["encoder_hidden_states"][0:1].cuda(), None
+
+            def image_latents(self, image, num_frames, height, width):
+                idx, fr, first = image
+                return cond["image_latents_first" if first else "image_latents"][idx:idx + 1].cuda()
+
+            def encode_image(self, image):
+                idx, fr, first = image
+                return cond["image_embeddings"][idx:idx + 1, fr:fr + 1].cuda()
+
+        pipe.conditioner = Cond()
+        out = pipe.sample_with_pnp_pipeline_with_edit_prompt_extraction_with_attn_injection(
+            prompt="edit", main_first_image=(3, 0, True), main_image_list=[(3, k, False) for k in range(f)],
+            background_first_image=(0, 0, True), background_image_list=[(0, k, False) for k in range(f)],
+            objs_first_image=[(1, 0, True), (2, 0, True)],
+            objs_image_list=[[(1, k, False) for k in range(f)], [(2, k, False) for k in range(f)]],
+            height=h * 8, width=w * 8, num_frames=f, num_inference_steps=n, guidance_scale=1.0, negative_prompt="neg", target_fps=8,
+            latents=x0.cuda(), output_type="latent", ddim_init_latents_t_idx=0, ddim_inv_prompt="", fusion_steps=(0, 1),
+            random_noise_ratio=0.0, bg_inv_latents_path="/virtual/src0", obj_ddim_latents_path=["/virtual/src1", "/virtual/src2"],
+            obj_ddim_latents_idx_offset=[0, 0], obj_masks_tensors=masks).frames
+        d = float((out.cpu().float() - ref.float()).abs().max())
+        print(f"CFG-off composition after {n} steps (graphs={graphs}): max-abs {d:.2e}")
+        assert d < 3e-2, d
+        results.append(out)
+    assert torch.equal(results[0], results[1])
+    for site in eng.hook_sites():
+        site.injection_schedule, site.t, site.mask = None, None, None
