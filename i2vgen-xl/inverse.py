@@ -48,11 +48,17 @@ def ddim_sampling(config, first_frame, ddim_latents_at_T, pipe, ddim_scheduler, 
 
 
 def build_pipeline(device, synthetic):
+    from mvoc_amd.vae import attach_vae
     if synthetic or not os.path.isdir(os.path.join(PRETRAINED_MODEL_PATH, "unet")):
         if not synthetic:
             logger.warning(f"{PRETRAINED_MODEL_PATH}/unet not found: using seeded synthetic UNet weights")
-        return I2VGenXLPipeline.synthetic(device=device)
-    return I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=torch.float16, variant="fp16", device=device)
+        pipe = I2VGenXLPipeline.synthetic(device=device)
+    else:
+        pipe = I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=torch.float16, variant="fp16", device=device)
+    # VAE encode / decode either side of the loops (frames in, frames out): the checkpoint's vae/ when present; with
+    # MVOC_SYNTHETIC_VAE=1 seeded weights of the same architecture; otherwise the drivers keep latents
+    attach_vae(pipe, PRETRAINED_MODEL_PATH, synthetic=os.environ.get("MVOC_SYNTHETIC_VAE") == "1")
+    return pipe
 
 
 def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch):

@@ -72,6 +72,9 @@ typedef struct mvoc_gemm_desc {
   const void* ln_rowsum;
   const void* ln_bias;
   float ln_eps;
+  int32_t pad_mode;     /* conv3x3: 0 = zero padding 1 on every side (F.conv2d(padding=1)); 1 = one row / column of zeros at the
+                           BOTTOM / RIGHT only (F.pad(x, (0,1,0,1)) + conv2d(padding=0, stride=2): the downsamplers of the VAE
+                           encoder, diffusers Downsample2D(padding=0)) */
   const void* ln_stats; /* optional {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (one read of the rows, shared by
                            every n-tile); NULL: each block accumulates the statistics of its rows in the K loop */
 } mvoc_gemm_desc;
@@ -214,6 +217,28 @@ int mvoc_tokens_to_ncfhw_f16(const void* x, void* out, int32_t b, int32_t c, int
  * params: fp16 blob {ln_g[4], ln_b[4], wq[8][4], wk[8][4], wv[8][4], wo[4][8], bo[4], w1[16][4], b1[16], w2[4][16], b2[4]} */
 int mvoc_temporal_encoder4_f16(const void* x, const void* params, void* out, int32_t b, int32_t f, int32_t hw,
                                int32_t ldo, int32_t coff, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VAE encode / decode either side of the loops (pipeline_i2vgen_xl.py:771-791 decode_latents, :860-890
+ * prepare_image_latents, :893-920 encode_vae_video -> diffusers AutoencoderKL).  The convolutions, GroupNorms and the
+ * mid-block attention's projections run through the entries above (mvoc_gemm_f16 incl. pad_mode = 1 for the encoder's
+ * Downsample2D(padding=0), mvoc_groupnorm_f16); what they need in addition:
+ * ------------------------------------------------------------------------------------------- */
+/* 1x1 conv over a handful of channels on channels-last rows: out[r][o] = sum_c x[r][c] w[o][c] + bias[o]
+ * (AutoencoderKL.quant_conv 8 -> 8, post_quant_conv 4 -> 4); cin, cout <= 64 */
+int mvoc_conv1x1_small_f16(const void* x, const void* w, const void* bias, void* out, int64_t rows, int32_t cin,
+                           int32_t cout, void* stream);
+/* in-place softmax over the rows of a contiguous [rows][cols] fp16 matrix (fp32 math): the score matrix of the VAE's
+ * single-head attention (head_dim 512; Attention(residual_connection=True) in UNetMidBlock2D), cols % 8 == 0 */
+int mvoc_softmax_rows_f16(void* x, int64_t rows, int32_t cols, void* stream);
+/* vae.encode(x).latent_dist.sample() (diffusers DiagonalGaussianDistribution): out = mean + exp(0.5*clamp(logvar,-30,20)) * noise,
+ * each eager fp16 op rounded; and python-float * fp16 tensor (latents * scaling_factor, 1/scaling_factor * latents:
+ * pipeline_i2vgen_xl.py:772, 869, 911) with the reference's fp32-then-fp16 double rounding */
+int mvoc_gaussian_sample_f16(const void* mean, const void* logvar, const void* noise, void* out, int64_t n, void* stream);
+int mvoc_scale_f16(const void* x, void* out, int64_t n, double scale, void* stream);
+/* [n][c][hw] images / latents (reference NCHW) <-> channels-last rows [n*hw][c] (ld >= c on the way back) */
+int mvoc_image_to_tokens_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, void* stream);
+int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, int32_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("nimg", i32), ("hout", i32), ("wout", i32), ("hsrc", i32), ("wsrc", i32), ("stride", i32),
                 ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
                 ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("ln_rowsum", vp), ("ln_bias", vp),
-                ("ln_eps", f32), ("ln_stats", vp)]
+                ("ln_eps", f32), ("pad_mode", i32), ("ln_stats", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -83,6 +83,12 @@ SIGNATURES = {
     "mvoc_ncfhw_to_tokens_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mvoc_tokens_to_ncfhw_f16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mvoc_temporal_encoder4_f16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mvoc_conv1x1_small_f16": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "mvoc_softmax_rows_f16": (i32, [vp, i64, i32, vp]),
+    "mvoc_gaussian_sample_f16": (i32, [vp, vp, vp, vp, i64, vp]),
+    "mvoc_scale_f16": (i32, [vp, vp, i64, f64, vp]),
+    "mvoc_image_to_tokens_f16": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mvoc_tokens_to_image_f16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mvoc_prof_enable": (i32, [i32]),
     "mvoc_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "mvoc_prof_reset": (i32, []),

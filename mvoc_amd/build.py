@@ -40,21 +40,31 @@ def build(force=False, verbose=True):
         return LIB
     objs = []
     procs = []
+    shared = b"".join(open(os.path.join(CSRC, f), "rb").read() for f in sorted(os.listdir(CSRC)) if f.endswith(".h"))
+    shared += open(os.path.join(HERE, "..", "include", "mvoc_hip.h"), "rb").read()
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".lab.o" if LAB else ".o"))
+        objs.append(obj)
         cmd = [HIPCC, *FLAGS, *(["-DMVOC_PP_LAB"] if LAB else []), *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        # per-object digest (source + every header + the command line): unchanged translation units are not recompiled
+        od = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + shared + " ".join(cmd).encode()).hexdigest()
+        ostamp = obj + ".stamp"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == od:
+            continue
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), ostamp, od))
     failed = False
-    for src, p in procs:
+    for src, p, ostamp, od in procs:
         out, _ = p.communicate()
         if out.strip() and verbose:
             print(out)
         if p.returncode != 0:
             failed = True
             print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
+        else:
+            with open(ostamp, "w") as fh:
+                fh.write(od)
     if failed:
         raise RuntimeError("libmvoc_hip.so: compilation failed")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -309,8 +309,8 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_kernel(const GemmArgs p) {
         const int rem = m - img * hwout;
         const int oy = rem / p.wout;
         ri[i].img = img;
-        ri[i].y0 = oy * p.stride - 1;
-        ri[i].x0 = (rem - oy * p.wout) * p.stride - 1;
+        ri[i].y0 = oy * p.stride - p.pad;
+        ri[i].x0 = (rem - oy * p.wout) * p.stride - p.pad;
       } else if (p.a_mode == MVOC_A_TEMPORAL3) {
         ri[i].img = (m / p.hw) % p.frames;
       }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
       const int img = mm / hwout;
       const int rem = mm - img * hwout;
       const int oy = rem / p.wout;
-      const int y0 = oy * p.stride - 1, x0 = (rem - oy * p.wout) * p.stride - 1;
+      const int y0 = oy * p.stride - p.pad, x0 = (rem - oy * p.wout) * p.stride - p.pad;
       rimg[i] = img; ry0[i] = y0; rx0[i] = x0;
       rowoff[i] = (img * p.hsrc + y0) * p.wsrc + x0;
       unsigned mk = 0;
@@ -1012,6 +1012,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   a.a_mode = d->a_mode; a.lda = d->lda; a.lda2 = d->lda2; a.c1 = d->c1; a.cin = d->cin;
   a.nimg = d->nimg; a.hout = d->hout; a.wout = d->wout; a.hsrc = d->hsrc; a.wsrc = d->wsrc;
   a.stride = d->stride > 0 ? d->stride : 1; a.upsample = d->upsample;
+  a.pad = d->pad_mode == 1 ? 0 : 1;
   a.hup = d->upsample ? d->hup : d->hsrc; a.wup = d->upsample ? d->wup : d->wsrc;
   a.ups_sh = d->upsample ? (float)d->hsrc / (float)d->hup : 1.f;
   a.ups_sw = d->upsample ? (float)d->wsrc / (float)d->wup : 1.f;
@@ -1028,6 +1029,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
     MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");
     MVOC_REQUIRE(d->k >= 9 * (int64_t)d->cin, -1, "gemm: conv k < 9*cin");
+    MVOC_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && !d->upsample), -1, "gemm: pad_mode %d", d->pad_mode);
   } else if (d->a_mode == MVOC_A_TEMPORAL3) {
     MVOC_REQUIRE(d->frames > 0 && d->hw > 0 && d->m % ((int64_t)d->frames * d->hw) == 0, -1, "gemm: temporal dims");
     MVOC_REQUIRE(d->k == 3 * (int64_t)d->cin, -1, "gemm: temporal k != 3*cin");
@@ -1119,10 +1121,11 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     const bool pp_ok = d->k % 32 == 0 && d->cin % 32 == 0 && d->c1 % 32 == 0 && a.epi_lds &&
                        (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin) && !(d->ln_rowsum && !d->ln_stats);
     int pp = 0;
-    if (d->tile >= 91 && d->tile <= 94) {
+    if (d->tile >= 91 && d->tile <= 95) {
       MVOC_REQUIRE(pp_ok && !(d->tile == 92 && d->act == MVOC_ACT_GEGLU), -2,
-                   "gemm: tiles 91-94 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
-      pp = d->tile == 91 ? 256 : d->tile == 92 ? 320 : d->tile == 93 ? 2561 : 2562;  // 93 / 94: split LDS-DMA issue
+                   "gemm: tiles 91-95 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
+      // 93 / 94: split LDS-DMA issue; 95: MUBUF LDS-DMA (sources must span < 2 GB: 32-bit byte offsets)
+      pp = d->tile == 91 ? 256 : d->tile == 92 ? 320 : d->tile == 93 ? 2561 : d->tile == 94 ? 2562 : 2563;
     }
     if (pp) {
       a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;

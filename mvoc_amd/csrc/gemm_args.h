@@ -15,6 +15,7 @@ struct GemmArgs {
   int ldo, ldr, ld_rowadd, rowadd_div;
   int a_mode, lda, lda2, c1, cin;
   int nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
+  int pad;  // conv: leading (top / left) zero padding: 1, or 0 for the bottom/right-only padding of the VAE's downsamplers
   float ups_sh, ups_sw;
   int frames, hw;
   int act;

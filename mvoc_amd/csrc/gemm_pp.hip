@@ -52,7 +52,10 @@ __device__ __forceinline__ void wait_vm() {
 // SPLIT = how many of the wave's two activation pieces per stage are issued from inside its MFMA interval (between the 8th
 // and 9th MFMA) instead of its READ interval: a piece costs the issuing wave ~100 cycles, and four in a row made READ twice
 // as long as MFMA (in-kernel stamps, tools/pp_lab.py)
-template <int TN, int NS, bool LAB = false, int SPLIT = 0>
+// BUF: the LDS-DMA as MUBUF (buffer_load_dwordx4 ... offen lds: wave-uniform 128-bit resource + one 32-bit byte offset per lane)
+// instead of FLAT-global (64-bit address per lane).  Padding rows / taps outside the image / rows past M or N use an offset
+// beyond the resource's range: the hardware range check returns zeros, no zero page and no per-lane step are needed.
+template <int TN, int NS, bool LAB = false, int SPLIT = 0, bool BUF = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const int n_units) {
   constexpr int WM = 4, TM = 2;
   constexpr int BN = 2 * TN * 32, BM = WM * TM * 32;
@@ -87,6 +90,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
   int wstep[PWMAX];
   const half_t* aptr[2];
   int astep[2];
+  unsigned woff[PWMAX], aoff[2];  // BUF: byte offsets into the weight / activation resources
+  constexpr unsigned OOB = 0x80000000u;  // >= num_records: the load returns zeros
+  bool a_second = false;
+  __amdgpu_buffer_rsrc_t rs_w, rs_a, rs_a2;
+  if constexpr (BUF) {
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)OOB, 0x00020000);
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)OOB, 0x00020000);
+    rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)OOB, 0x00020000);
+  }
   int rowoff[2];
   unsigned vmask[2];
   int ry0[2], rx0[2], rimg[2];
@@ -109,9 +121,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
     for (int i = 0; i < PWMAX; ++i) {
       const int row = (wave + 8 * i) * 16 + lrow;
       const bool ok = row < BN && n0 + row < p.N;
-      wptr[i] = ok ? p.w + (size_t)(n0 + row) * p.K + cch + kbeg : zsrc;
-      wstep[i] = ok ? KS : 0;
-      if (LAB && (p.lab & 2)) { wptr[i] = zsrc; wstep[i] = 0; }
+      if constexpr (BUF) {
+        woff[i] = ok ? (unsigned)(((size_t)(n0 + row) * p.K + cch + kbeg) * 2) : OOB;
+      } else {
+        wptr[i] = ok ? p.w + (size_t)(n0 + row) * p.K + cch + kbeg : zsrc;
+        wstep[i] = ok ? KS : 0;
+        if (LAB && (p.lab & 2)) { wptr[i] = zsrc; wstep[i] = 0; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
         const int img = mm / hwout;
         const int rem = mm - img * hwout;
         const int oy = rem / p.wout;
-        const int y0 = oy * p.stride - 1, x0 = (rem - oy * p.wout) * p.stride - 1;
+        const int y0 = oy * p.stride - p.pad, x0 = (rem - oy * p.wout) * p.stride - p.pad;
         rimg[i] = img; ry0[i] = y0; rx0[i] = x0;
         rowoff[i] = (img * p.hsrc + y0) * p.wsrc + x0;
         unsigned mk = 0;
@@ -157,10 +173,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
     char* base = smem + slot * STAGE;
 #pragma unroll
     for (int i = 0; i < PWMAX; ++i) {
-      if (i < npw)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[i],
-                                         (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
-      wptr[i] += wstep[i];
+      if constexpr (BUF) {
+        if (i < npw)  // wave-uniform
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16,
+                                                   (int)woff[i], 0, 0, 0);
+        woff[i] += KS * 2;  // (an out-of-range offset stays out of range)
+      } else {
+        if (i < npw)  // wave-uniform
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[i],
+                                           (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+        wptr[i] += wstep[i];
+      }
     }
     if (regather) {  // wave-uniform: first stage of a unit, a new tap, or the switch to the second source
       const bool second = p_ch0 >= p.c1;
@@ -180,16 +203,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
           const int ix = min((int)floorf((rx0[i] + kx) * p.ups_sw), p.wsrc - 1);
           srow = ((long)rimg[i] * p.hsrc + iy) * p.wsrc + ix;
         }
-        aptr[i] = ok ? sbase + srow * ld + (cbase + cch) : zsrc;
-        astep[i] = ok ? KS : 0;
-        if (LAB && (p.lab & 2)) { aptr[i] = zsrc; astep[i] = 0; }
+        if constexpr (BUF) {
+          aoff[i] = ok ? (unsigned)((srow * ld + (cbase + cch)) * 2) : OOB;
+          a_second = second;
+        } else {
+          aptr[i] = ok ? sbase + srow * ld + (cbase + cch) : zsrc;
+          astep[i] = ok ? KS : 0;
+          if (LAB && (p.lab & 2)) { aptr[i] = zsrc; astep[i] = 0; }
+        }
       }
     }
   };
   auto issue_a = [&](int slot, int i) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
-                                     (__attribute__((address_space(3))) void*)(smem + slot * STAGE + BN * ROWB + (wave + 8 * i) * 1024), 16, 0, 0);
-    aptr[i] += astep[i];
+    if constexpr (BUF) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_second ? rs_a2 : rs_a,
+                                               (__attribute__((address_space(3))) void*)(smem + slot * STAGE + BN * ROWB + (wave + 8 * i) * 1024),
+                                               16, (int)aoff[i], 0, 0, 0);
+      aoff[i] += KS * 2;
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
+                                       (__attribute__((address_space(3))) void*)(smem + slot * STAGE + BN * ROWB + (wave + 8 * i) * 1024), 16, 0, 0);
+      aptr[i] += astep[i];
+    }
   };
   auto end_stage = [&]() {  // scalar bookkeeping only
     p_ch0 += KS;
@@ -491,7 +526,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmArgs p, const in
   }
 }
 
-template <int TN, int NS, bool LAB = false, int SPLIT = 0>
+template <int TN, int NS, bool LAB = false, int SPLIT = 0, bool BUF = false>
 int launch_pp(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   constexpr int BN = 2 * TN * 32, BM = 256;
@@ -510,7 +545,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t s) {
     ncu = v;
   }
   const int grid = (int)(units < ncu ? units : ncu);
-  hipLaunchKernelGGL((gemm_pp_kernel<TN, NS, LAB, SPLIT>), dim3((unsigned)grid), dim3(512), 0, s, a, (int)units);
+  hipLaunchKernelGGL((gemm_pp_kernel<TN, NS, LAB, SPLIT, BUF>), dim3((unsigned)grid), dim3(512), 0, s, a, (int)units);
   return mvoc_check_launch("gemm_pp_kernel");
 }
 
@@ -523,6 +558,7 @@ int mvoc_launch_gemm_pp(const GemmArgs& a, int bn, hipStream_t s) {
   if (bn == 256) return launch_pp<4, 4>(a, s);
   if (bn == 2561) return launch_pp<4, 4, false, 1>(a, s);
   if (bn == 2562) return launch_pp<4, 4, false, 2>(a, s);
+  if (bn == 2563) return launch_pp<4, 4, false, 0, true>(a, s);
   if (bn == 320) return launch_pp<5, 3>(a, s);
   mvoc_set_error("gemm_pp: unsupported tile width %d", bn);
   return -1;

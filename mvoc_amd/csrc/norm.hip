@@ -330,6 +330,49 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict
 
 }  // namespace
 
+// row softmax, in place (the score matrix of the VAE's single-head mid-block attention, head_dim 512): one wave per row,
+// fp32 max / exp / sum, one rounding to fp16
+namespace {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, long rows, int cols) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  half_t* xr = x + row * cols;
+  const int nch = cols / 8;
+  float mx = -3.0e38f;
+  for (int c = lane; c < nch; c += 64) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[e]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const half8_t v = *reinterpret_cast<const half8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __expf((float)v[e] - mx);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < nch; c += 64) {
+    half8_t v = *reinterpret_cast<const half8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (half_t)(__expf((float)v[e] - mx) * inv);
+    *reinterpret_cast<half8_t*>(xr + c * 8) = v;
+  }
+}
+}  // namespace
+
+extern "C" int mvoc_softmax_rows_f16(void* x, int64_t rows, int32_t cols, void* stream) {
+  MVOC_REQUIRE(x && rows > 0 && cols > 0 && cols % 8 == 0 && ((uintptr_t)x & 15) == 0, -1, "softmax_rows: bad args (cols %% 8, 16-byte aligned)");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * rows * cols);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (half_t*)x, (long)rows, cols);
+  return mvoc_check_launch("softmax_rows_kernel");
+}
+
 extern "C" int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream) {
   MVOC_REQUIRE(x && stats && rows > 0 && c >= 8 && c % 8 == 0, -1, "row_stats: bad args");
   hipStream_t s = (hipStream_t)stream;

@@ -249,6 +249,99 @@ extern "C" int mvoc_conv3x3_small_f16(const void* x, const void* w, const void* 
   return mvoc_check_launch("conv3x3_small_kernel");
 }
 
+// ---- VAE helpers -------------------------------------------------------------------------------------
+// 1x1 conv over a handful of channels (AutoencoderKL.quant_conv 8 -> 8, post_quant_conv 4 -> 4): thread = (row, cout)
+__global__ void conv1x1_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w, const half_t* __restrict__ bias,
+                                     half_t* __restrict__ out, long rows, int cin, int cout) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cout) return;
+  const int co = (int)(i % cout);
+  const long r = i / cout;
+  float acc = 0.f;
+  for (int c = 0; c < cin; ++c) acc += (float)x[r * cin + c] * (float)w[co * cin + c];
+  out[i] = (half_t)(acc + (bias ? (float)bias[co] : 0.f));
+}
+
+// [n][c][hw] fp16 (reference NCHW images / latents) <-> channels-last rows [n*hw][ld]
+__global__ void image_to_tokens_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int n, int c, int hw) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * hw * c) return;
+  const int ch = (int)(i % c);
+  const long px = i / c;
+  const int img = (int)(px / hw), p = (int)(px % hw);
+  out[i] = x[((long)img * c + ch) * hw + p];
+}
+__global__ void tokens_to_image_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int n, int c, int hw, int ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * c * hw) return;
+  const int p = (int)(i % hw);
+  const long t = i / hw;
+  const int ch = (int)(t % c), img = (int)(t / c);
+  out[i] = x[((long)img * hw + p) * ld + ch];
+}
+
+// DiagonalGaussianDistribution.sample() on fp16 tensors, one rounding per eager op: std = exp(0.5 * clamp(logvar, -30, 20));
+// x = mean + std * noise
+__global__ void gaussian_sample_kernel(const half_t* __restrict__ mean, const half_t* __restrict__ logvar,
+                                       const half_t* __restrict__ noise, half_t* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lv = fminf(fmaxf((float)logvar[i], -30.0f), 20.0f);
+  const float sd = r16(expf(r16(0.5f * lv)));
+  out[i] = (half_t)((float)mean[i] + r16(sd * (float)noise[i]));
+}
+// python-float x fp16 tensor (fp32 product rounded to fp32, then to fp16: the pinned VGPR keeps hipcc from fusing the two)
+__global__ void scale_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, long n, float s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p = s * (float)x[i];
+  asm volatile("" : "+v"(p));
+  out[i] = (half_t)p;
+}
+
+extern "C" int mvoc_gaussian_sample_f16(const void* mean, const void* logvar, const void* noise, void* out, int64_t n, void* stream) {
+  MVOC_REQUIRE(mean && logvar && noise && out && n > 0, -1, "gaussian_sample: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 8.0 * n);
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(nblk(n)), dim3(256), 0, s, (const half_t*)mean, (const half_t*)logvar,
+                     (const half_t*)noise, (half_t*)out, (long)n);
+  return mvoc_check_launch("gaussian_sample_kernel");
+}
+
+extern "C" int mvoc_scale_f16(const void* x, void* out, int64_t n, double scale, void* stream) {
+  MVOC_REQUIRE(x && out && n > 0, -1, "scale: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * n);
+  hipLaunchKernelGGL(scale_kernel, dim3(nblk(n)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, (long)n, (float)scale);
+  return mvoc_check_launch("scale_kernel");
+}
+
+extern "C" int mvoc_conv1x1_small_f16(const void* x, const void* w, const void* bias, void* out, int64_t rows, int32_t cin,
+                                      int32_t cout, void* stream) {
+  MVOC_REQUIRE(x && w && out && rows > 0 && cin > 0 && cout > 0 && cin <= 64 && cout <= 64, -1, "conv1x1_small: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 2.0 * rows * (cin + cout));
+  hipLaunchKernelGGL(conv1x1_small_kernel, dim3(nblk(rows * cout)), dim3(256), 0, s, (const half_t*)x, (const half_t*)w,
+                     (const half_t*)bias, (half_t*)out, (long)rows, cin, cout);
+  return mvoc_check_launch("conv1x1_small_kernel");
+}
+
+extern "C" int mvoc_image_to_tokens_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, void* stream) {
+  MVOC_REQUIRE(x && out && n > 0 && c > 0 && hw > 0, -1, "image_to_tokens: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * n * c * hw);
+  hipLaunchKernelGGL(image_to_tokens_kernel, dim3(nblk((long)n * c * hw)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, n, c, hw);
+  return mvoc_check_launch("image_to_tokens_kernel");
+}
+
+extern "C" int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, int32_t ld, void* stream) {
+  MVOC_REQUIRE(x && out && n > 0 && c > 0 && hw > 0 && ld >= c, -1, "tokens_to_image: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * n * c * hw);
+  hipLaunchKernelGGL(tokens_to_image_kernel, dim3(nblk((long)n * c * hw)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, n, c, hw, ld);
+  return mvoc_check_launch("tokens_to_image_kernel");
+}
+
 extern "C" int mvoc_adaptive_avgpool_f16(const void* x, void* out, int32_t nimg, int32_t h, int32_t w, int32_t c,
                                          int32_t oh, int32_t ow, void* stream) {
   MVOC_REQUIRE(x && out && nimg > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, -1, "avgpool: bad args");

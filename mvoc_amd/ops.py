@@ -13,7 +13,7 @@ from ._ffi import (A_CONV3X3, A_PLAIN, A_TEMPORAL3, ACT_GEGLU, ACT_GELU, ACT_NON
 
 __all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "groupnorm_moments", "groupnorm_apply_moments", "layernorm", "pnp_blend_tokens",
            "pnp_blend_nchw", "ddim_step", "latent_fusion", "timestep_embedding", "act", "add", "conv3x3_small",
-           "adaptive_avgpool", "ncfhw_to_tokens", "tokens_to_ncfhw", "temporal_encoder4", "ACT_NONE", "ACT_GEGLU",
+           "adaptive_avgpool", "ncfhw_to_tokens", "tokens_to_ncfhw", "temporal_encoder4", "conv1x1_small", "softmax_rows", "ACT_NONE", "ACT_GEGLU",
            "ACT_SILU", "ACT_GELU"]
 
 
@@ -105,16 +105,18 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
 
 
 def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
-            n_store=0, out=None, tile=0, split_k=0):
+            n_store=0, out=None, tile=0, split_k=0, pad_mode=0):
     """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
-    ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D)."""
+    ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D).
+    ``pad_mode=1``: zeros at the bottom / right only (``F.pad(x, (0,1,0,1))`` + ``conv2d(padding=0)``: VAE downsamplers)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
     _rowmajor(x, "x")
     c1 = x.shape[1]
     cin = c1 + (x2.shape[1] if x2 is not None else 0)
     hup, wup = (upsample_to if upsample_to is not None else (h, wd))
-    ho = (hup + 2 - 3) // stride + 1
-    wo = (wup + 2 - 3) // stride + 1
+    pt = 2 if pad_mode == 0 else 1  # total padding per axis
+    ho = (hup + pt - 3) // stride + 1
+    wo = (wup + pt - 3) // stride + 1
     m = nimg * ho * wo
     cols = _out_cols(w, n_store, ACT_NONE)
     if out is None:
@@ -128,6 +130,7 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
     d.upsample = 1 if upsample_to is not None else 0
     d.hup, d.wup = hup, wup
     d.split_k = split_k
+    d.pad_mode = pad_mode
     _gemm(d, x.device)
     return out, ho, wo
 
@@ -362,6 +365,43 @@ def temporal_encoder4(x, params, out, *, b, f, hw, coff):
     check(lib.mvoc_temporal_encoder4_f16(x.data_ptr(), params.data_ptr(), out.data_ptr(), b, f, hw, out.stride(0), coff,
                                          _stream()), "temporal_encoder4")
     return out
+
+
+def conv1x1_small(x, w, bias):
+    """out[r, o] = sum_c x[r, c] * w[o, c] + bias[o] for a handful of channels (the VAE's quant / post_quant 1x1 convs)"""
+    _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias")
+    if not x.is_contiguous() or x.shape[1] != w.shape[1]:
+        raise RuntimeError("conv1x1_small: x must be contiguous [rows, cin] with cin == w.shape[1]")
+    out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_conv1x1_small_f16(x.data_ptr(), w.contiguous().data_ptr(), _ptr(bias), out.data_ptr(), x.shape[0], x.shape[1],
+                                     w.shape[0], _stream()), "conv1x1_small")
+    return out
+
+
+def image_to_tokens(x):
+    """[n, c, h, w] fp16 -> channels-last rows [n*h*w, c]"""
+    _chk(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n * h * w, c), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_image_to_tokens_f16(x.contiguous().data_ptr(), out.data_ptr(), n, c, h * w, _stream()), "image_to_tokens")
+    return out
+
+
+def tokens_to_image(x, n, c, h, w):
+    """channels-last rows [n*h*w, ld] (first c channels) -> [n, c, h, w]"""
+    _chk(x, "x")
+    out = torch.empty((n, c, h, w), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_tokens_to_image_f16(x.data_ptr(), out.data_ptr(), n, c, h * w, _rowmajor(x, "x"), _stream()), "tokens_to_image")
+    return out
+
+
+def softmax_rows(x):
+    """in-place softmax over the last dim of a contiguous [rows, cols] fp16 matrix (fp32 math, one rounding)"""
+    _chk(x, "x")
+    if x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("softmax_rows: x must be contiguous [rows, cols]")
+    check(lib.mvoc_softmax_rows_f16(x.data_ptr(), x.shape[0], x.shape[1], _stream()), "softmax_rows")
+    return x
 
 
 def prof_enable(on):

@@ -43,9 +43,12 @@ class SyntheticConditioner:
     cross_attention_dim = 1024
     vae_scale_factor = 8
 
-    def __init__(self, device, cross_attention_dim=1024):
+    def __init__(self, device, cross_attention_dim=1024, vae=None):
+        """``vae``: a ``mvoc_amd.vae.VaeCodec`` -- video / image latents and decoding then go through the HIP VAE
+         instead of the seeded stand-ins; the CLIP halves stay synthetic (8f-3 is not built)"""
         self.device = torch.device(device)
         self.cross_attention_dim = cross_attention_dim
+        self.vae = vae
 
     def _gen(self, *keys):
         h = hashlib.sha256("|".join(str(k) for k in keys).encode()).digest()
@@ -68,6 +71,8 @@ class SyntheticConditioner:
         return torch.randn(1, 1, self.cross_attention_dim, generator=self._gen("i", self._image_key(image))).to(self.device, H16)
 
     def image_latents(self, image, num_frames, height, width):
+        if self.vae is not None and hasattr(image, "convert"):
+            return self.vae.image_latents(image, num_frames, height, width)
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         first = 0.18215 * torch.randn(1, 4, 1, h, w, generator=self._gen("l", self._image_key(image), h, w))
         if num_frames > 1:
@@ -76,12 +81,17 @@ class SyntheticConditioner:
         return first.to(self.device, H16)
 
     def encode_video(self, frames, height, width):
+        if self.vae is not None and all(hasattr(f, "convert") for f in frames):
+            return self.vae.encode_video(frames, height, width)
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         lat = [0.18215 * 4 * torch.randn(4, h, w, generator=self._gen("v", self._image_key(f), h, w)) for f in frames]
         return torch.stack(lat, 1)[None].to(self.device, H16)
 
     def decode(self, latents):
-        raise NotImplementedError("VAE decode is a 'next' row (SURVEY 8f-1): pass output_type='latent'")
+        """-> video [B,3,F,H,W] float32 in about [-1,1] (``decode_latents``, ``pipeline_i2vgen_xl.py:771-791``)"""
+        if self.vae is None:
+            raise NotImplementedError("this conditioner has no VAE (SyntheticConditioner(vae=VaeCodec(...))): pass output_type='latent'")
+        return self.vae.decode(latents)
 
 
 class GraphedStep:
@@ -334,8 +344,13 @@ class I2VGenXLPipeline:
                                         negative_prompt_embeds, image_embeddings, image_latents)
         latents = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, generator, latents)
         latents = self._run_stock_loop(latents, cond, num_inference_steps, guidance_scale, first_idx=ddim_init_latents_t_idx)
-        frames = latents if output_type == "latent" else self.conditioner.decode(latents)
+        frames = latents if output_type == "latent" else self._to_video(latents, output_type)
         return PipelineOutput(frames=frames) if return_dict else (frames,)
+
+    def _to_video(self, latents, output_type):
+        """``decode_latents`` + ``tensor2vid`` (``pipeline_i2vgen_xl.py:1207-1208``): per batch entry a list of PIL frames"""
+        from .vae import tensor2vid
+        return tensor2vid(self.conditioner.decode(latents), output_type)
 
     # ---- composition --------------------------------------------------------------------------------------
     def make_composition_state(self, latents, cond, masks, guidance_scale):
@@ -465,5 +480,5 @@ class I2VGenXLPipeline:
                 objs = [cache.get(obj_ddim_latents_path[j], t) for j in range(n_obj)]
             self.composition_step(st, t, bg, objs, table[index[t]], fuse)
         latents = st["latents"].clone()
-        frames = latents if output_type == "latent" else c.decode(latents)
+        frames = latents if output_type == "latent" else self._to_video(latents, output_type)
         return PipelineOutput(frames=frames) if return_dict else (frames,)

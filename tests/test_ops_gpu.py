@@ -252,7 +252,7 @@ def test_tconv3(ops, frames, tile):
 # time-embedding row add and the residual.  Operands are small integers: every product and every fp32 partial sum is
 # exact and |result| < 2048 is exact in fp16, so the comparison with torch's CPU conv is BIT-EXACT -- any indexing slip in
 # a tile (tap order, source switch, swizzle, tail rows) shows as a wrong integer.
-PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 91, 92, 93, 94]
+PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 91, 92, 93, 94, 95]
 _prod_cache = {}
 
 
