@@ -241,6 +241,24 @@ int mvoc_image_to_tokens_f16(const void* x, void* out, int32_t n, int32_t c, int
 int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, int32_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * RCCL exchanges of the frame-axis shard (SURVEY 8b `allgather_frames`, 8e / BASELINE configs[3]: one long clip over the GPUs
+ * of a node; the reference has no collective -- this is new work north_star asks for).  One process per GPU; rank 0 makes a
+ * 128-byte id (mvoc_comm_unique_id), the host distributes it by any means, every rank calls mvoc_comm_init.  The exchanges
+ * are asynchronous on `stream` and capturable; RCCL is resolved at run time (the copy PyTorch-ROCm already loaded, else
+ * librccl.so.1), so the library loads without it and these entries then return -3.
+ *   allgather: rank r's `bytes_per_rank` bytes land at recv + r*bytes_per_rank on every rank (temporal attention's K/V form)
+ *   alltoall : send + j*bytes_per_peer goes to rank j, recv + i*bytes_per_peer came from rank i (frame shard <-> pixel shard)
+ * ------------------------------------------------------------------------------------------- */
+/* packing around the exchanges: out rows contiguous over (i0,i1,i2,i3) < dims4, source row = sum_k i_k * strides4[k]
+ * (rows of c fp16, c % 8 == 0) -- frame shard [B,F/N,HW,C] <-> per-peer blocks <-> pixel shard [B,F,HW/N,C] */
+int mvoc_permute_rows_f16(const void* x, void* out, const int64_t* dims4, const int64_t* strides4, int32_t c, void* stream);
+int mvoc_comm_unique_id(void* id128);
+int mvoc_comm_init(const void* id128, int32_t rank, int32_t world, void** comm);
+int mvoc_comm_destroy(void* comm);
+int mvoc_allgather_frames(void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int mvoc_alltoall_frames(void* comm, const void* send, void* recv, size_t bytes_per_peer, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).
  * ------------------------------------------------------------------------------------------- */
 enum { MVOC_FAM_GEMM = 0, MVOC_FAM_FLASH = 1, MVOC_FAM_TATTN = 2, MVOC_FAM_GN = 3, MVOC_FAM_LN = 4, MVOC_FAM_PNP = 5,

@@ -89,6 +89,12 @@ SIGNATURES = {
     "mvoc_scale_f16": (i32, [vp, vp, i64, f64, vp]),
     "mvoc_image_to_tokens_f16": (i32, [vp, vp, i32, i32, i32, vp]),
     "mvoc_tokens_to_image_f16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "mvoc_permute_rows_f16": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), i32, vp]),
+    "mvoc_comm_unique_id": (i32, [vp]),
+    "mvoc_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "mvoc_comm_destroy": (i32, [vp]),
+    "mvoc_allgather_frames": (i32, [vp, vp, vp, sz, vp]),
+    "mvoc_alltoall_frames": (i32, [vp, vp, vp, sz, vp]),
     "mvoc_prof_enable": (i32, [i32]),
     "mvoc_prof_collect": (i32, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
     "mvoc_prof_reset": (i32, []),

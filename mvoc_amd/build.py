@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvoc_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "norm.hip", "pnp.hip", "stem.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LAB = os.environ.get("MVOC_BUILD_LAB") == "1"  # diagnostic library (in-kernel stamps / ablations): libmvoc_hip_lab.so
 if LAB:
@@ -67,7 +67,7 @@ def build(force=False, verbose=True):
                 fh.write(od)
     if failed:
         raise RuntimeError("libmvoc_hip.so: compilation failed")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -342,6 +342,33 @@ extern "C" int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int
   return mvoc_check_launch("tokens_to_image_kernel");
 }
 
+// row permutation copy (frame shard <-> pixel shard packing around the RCCL exchanges): out rows are contiguous over the index
+// (i0,i1,i2,i3); the source row of each is i0*s0 + i1*s1 + i2*s2 + i3*s3; thread = 16-byte chunk of a row
+__global__ void permute_rows_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int d1, int d2, int d3, long s0, long s1,
+                                    long s2, long s3, int c8n, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % c8n);
+  long r = i / c8n;
+  const int i3 = (int)(r % d3); r /= d3;
+  const int i2 = (int)(r % d2); r /= d2;
+  const int i1 = (int)(r % d1);
+  const long i0 = r / d1;
+  const long src = i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3;
+  reinterpret_cast<half8_t*>(out)[i] = *reinterpret_cast<const half8_t*>(x + (src * c8n + c8) * 8);
+}
+
+extern "C" int mvoc_permute_rows_f16(const void* x, void* out, const int64_t* dims4, const int64_t* strides4, int32_t c, void* stream) {
+  MVOC_REQUIRE(x && out && dims4 && strides4 && c > 0 && c % 8 == 0, -1, "permute_rows: bad args (c %% 8)");
+  for (int k = 0; k < 4; ++k) MVOC_REQUIRE(dims4[k] > 0 && dims4[k] < (1 << 30), -1, "permute_rows: bad dim");
+  const long total = (long)dims4[0] * dims4[1] * dims4[2] * dims4[3] * (c / 8);
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 32.0 * total);
+  hipLaunchKernelGGL(permute_rows_kernel, dim3(nblk(total)), dim3(256), 0, s, (const half_t*)x, (half_t*)out, (int)dims4[1], (int)dims4[2],
+                     (int)dims4[3], (long)strides4[0], (long)strides4[1], (long)strides4[2], (long)strides4[3], c / 8, total);
+  return mvoc_check_launch("permute_rows_kernel");
+}
+
 extern "C" int mvoc_adaptive_avgpool_f16(const void* x, void* out, int32_t nimg, int32_t h, int32_t w, int32_t c,
                                          int32_t oh, int32_t ow, void* stream) {
   MVOC_REQUIRE(x && out && nimg > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, -1, "avgpool: bad args");

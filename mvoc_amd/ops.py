@@ -395,6 +395,20 @@ def tokens_to_image(x, n, c, h, w):
     return out
 
 
+def permute_rows(x, shape4, perm):
+    """x: contiguous [prod(shape4), c] rows viewed as [*shape4, c]; returns the rows of ``x.view(*shape4, c).permute(*perm, 4)``
+    made contiguous ([prod, c]) -- the pack / unpack copies around the frame-shard exchanges as one HIP kernel"""
+    _chk(x, "x")
+    if not x.is_contiguous() or x.dim() != 2:
+        raise RuntimeError("permute_rows: x must be contiguous [rows, c]")
+    st = [shape4[1] * shape4[2] * shape4[3], shape4[2] * shape4[3], shape4[3], 1]
+    dims = (C.c_int64 * 4)(*[shape4[p] for p in perm])
+    strides = (C.c_int64 * 4)(*[st[p] for p in perm])
+    out = torch.empty_like(x)
+    check(lib.mvoc_permute_rows_f16(x.data_ptr(), out.data_ptr(), dims, strides, x.shape[1], _stream()), "permute_rows")
+    return out
+
+
 def softmax_rows(x):
     """in-place softmax over the last dim of a contiguous [rows, cols] fp16 matrix (fp32 math, one rounding)"""
     _chk(x, "x")

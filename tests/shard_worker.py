@@ -160,6 +160,39 @@ def pipeline(out_dir):
               open(os.path.join(out_dir, f"pipeline_r{rank}.json"), "w"))
 
 
+def rccl_native(out_dir):
+    """the library's own RCCL communicator (C ABI mvoc_comm_* / mvoc_allgather_frames / mvoc_alltoall_frames): with the world
+    this test box allows (one GPU -> one rank) the exchanges are identities, which checks symbol resolution, the id hand-off,
+    communicator life cycle and stream semantics; the engine then runs frame-sharded on that transport"""
+    from mvoc_amd.unet import I2VGenXLUNet
+    from mvoc_amd.unet_spec import UNetConfig
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    sh = FrameShard(transport="rccl")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2 * 4 * 6, 16, generator=g).half().to(dev)
+    px = sh.to_pixel_shard(x, 2, 4, 6)
+    back = sh.to_frame_shard(px, 2, 4, 6)
+    parts = sh.all_gather(x)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(back, x)) and tuple(parts.shape) == (world,) + tuple(x.shape) and bool(torch.equal(parts[rank], x))
+    cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
+                     attention_head_dim=64, transformer_in_heads=2, context_pool=8)
+    eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+    r = lambda *s_: torch.randn(*s_, generator=g).half().to(dev)
+    inp = (r(1, 4, 4, 16, 16), torch.tensor([500.0]).to(dev), torch.full((1,), 8.0).to(dev), r(1, 4, 4, 16, 16), r(1, 4, 4, 16, 16),
+           r(1, 4, 64), r(1, 7, 64))
+    ref = eng.forward_ext(*inp)[0]
+    eng.set_frame_shard(sh)
+    got = eng.forward_ext(*inp)[0]
+    eng.set_frame_shard(None)
+    torch.cuda.synchronize()
+    sh.close()
+    json.dump({"rank": rank, "exchanges_ok": ok, "forward_max_abs": float((got.float() - ref.float()).abs().max())},
+              open(os.path.join(out_dir, f"rccl_r{rank}.json"), "w"))
+
+
 if __name__ == "__main__":
     mode, out_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
@@ -168,6 +201,8 @@ if __name__ == "__main__":
             exchange(out_dir)
         elif mode == "pipeline":
             pipeline(out_dir)
+        elif mode == "rccl":
+            rccl_native(out_dir)
         else:
             unet(out_dir, sys.argv[3] if len(sys.argv) > 3 else "tiny")
         dist.barrier()

@@ -102,3 +102,26 @@ def test_sharded_inversion_loop_world2(tmp_path):
         rep = json.load(open(tmp_path / f"pipeline_r{rank}.json"))
         assert rep["max_abs"] <= 3e-2, rep
         assert rep["files"] == sorted(f"ddim_latents_{t}.pt" for t in (1, 201, 401, 601, 801)) and rep["files_match"], rep
+
+
+def test_permute_rows_kernel_matches_torch():
+    """the pack / unpack copies around the exchanges (one HIP kernel) against permute().contiguous()"""
+    import torch
+    from mvoc_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for shape4, perm in (((2, 3, 4, 5), (2, 0, 1, 3)), ((4, 2, 3, 5), (1, 0, 2, 3)), ((4, 2, 3, 5), (1, 2, 0, 3)), ((1, 7, 2, 9), (2, 0, 1, 3))):
+        n = shape4[0] * shape4[1] * shape4[2] * shape4[3]
+        x = torch.randn(n, 24, generator=g).half().cuda()
+        got = ops.permute_rows(x, shape4, perm)
+        ref = x.view(*shape4, 24).permute(*perm, 4).reshape(n, 24)
+        assert torch.equal(got, ref), (shape4, perm)
+
+
+def test_native_rccl_transport_world1(tmp_path):
+    """FrameShard(transport='rccl'): the C ABI's own communicator (mvoc_comm_init / mvoc_alltoall_frames /
+    mvoc_allgather_frames over the RCCL copy already in the process).  One GPU -> one rank: the exchanges are identities and
+    the frame-sharded forward must equal the unsharded one bit for bit"""
+    r = launch(1, 29556, "rccl", str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rep = json.load(open(tmp_path / "rccl_r0.json"))
+    assert rep["exchanges_ok"] and rep["forward_max_abs"] == 0.0, rep

@@ -243,6 +243,22 @@ def test_dropin_drivers_end_to_end(tmp_path):
     assert sub == ["ddim_init_latents_t_idx_0_nsteps_5_cfg_9.0_pnpf0.2_pnps1.0_pnpt1.0_ratio0.0noise_fusion_step0-1"]
     lat = torch.load(out_root / sub[0] / "video_latents.pt")
     assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
+    # with a VAE (seeded weights of the real architecture) the drivers go frames -> latents -> frames like the reference:
+    # the source clips are VAE-encoded (encode_vae_video), results are decoded and written as gif + png (composite.py:217-224)
+    os.environ["MVOC_SYNTHETIC_VAE"] = "1"
+    try:
+        tmpl3 = OmegaConf.load(os.path.join(REPO, "tests", "data", "inversion_template.yaml"))
+        tmpl3.data_dir = str(data)
+        tmpl3.inv_dir = "inversions_vae"
+        e3 = [dict(entries[0], recon_config={"enable_recon": True, "ddim_init_latents_t_idx": 1})]
+        inverse.main(tmpl3, e3, torch.device("cuda:0"), synthetic=True)
+        assert (data / "inversions_vae" / "i2vgen-xl" / "clipA" / "ddim_reconstruction.gif").exists()
+        composite.main(ct, [dict(centry, edited_video_name="out_frames")], torch.device("cuda:0"), synthetic=True)
+    finally:
+        del os.environ["MVOC_SYNTHETIC_VAE"]
+    fr = data / "Results" / "T" / "i2vgen-xl" / "clipA" / "out_frames" / sub[0]
+    assert sorted(os.listdir(fr)) == ["video.gif"] + [f"video_{i:05d}.png" for i in range(4)]
+    assert Image.open(fr / "video_00000.png").size == (64, 64)
 
 
 def test_invert_many_matches_separate_inversions(tmp_path):
