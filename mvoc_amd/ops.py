@@ -348,7 +348,8 @@ def ncfhw_to_tokens(x, out, coff=0):
     """x [B,C,F,h,w] -> out [B*F*h*w, ld] channels coff..coff+C"""
     _chk(x, "x"), _chk(out, "out")
     b, c, f, h, w = x.shape
-    check(lib.mvoc_ncfhw_to_tokens_f16(x.contiguous().data_ptr(), out.data_ptr(), b, c, f, h * w, out.stride(0), coff,
+    x = x.contiguous()  # (a copy, if one is made, is held until the launch is enqueued)
+    check(lib.mvoc_ncfhw_to_tokens_f16(x.data_ptr(), out.data_ptr(), b, c, f, h * w, out.stride(0), coff,
                                        _stream()), "ncfhw_to_tokens")
     return out
 
@@ -373,7 +374,8 @@ def conv1x1_small(x, w, bias):
     if not x.is_contiguous() or x.shape[1] != w.shape[1]:
         raise RuntimeError("conv1x1_small: x must be contiguous [rows, cin] with cin == w.shape[1]")
     out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float16, device=x.device)
-    check(lib.mvoc_conv1x1_small_f16(x.data_ptr(), w.contiguous().data_ptr(), _ptr(bias), out.data_ptr(), x.shape[0], x.shape[1],
+    w = w.contiguous()
+    check(lib.mvoc_conv1x1_small_f16(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), x.shape[0], x.shape[1],
                                      w.shape[0], _stream()), "conv1x1_small")
     return out
 
@@ -383,7 +385,8 @@ def image_to_tokens(x):
     _chk(x, "x")
     n, c, h, w = x.shape
     out = torch.empty((n * h * w, c), dtype=torch.float16, device=x.device)
-    check(lib.mvoc_image_to_tokens_f16(x.contiguous().data_ptr(), out.data_ptr(), n, c, h * w, _stream()), "image_to_tokens")
+    x = x.contiguous()
+    check(lib.mvoc_image_to_tokens_f16(x.data_ptr(), out.data_ptr(), n, c, h * w, _stream()), "image_to_tokens")
     return out
 
 

@@ -278,8 +278,9 @@ class AutoencoderKL:
             gdev = generator.device if generator is not None else mean.device
             noise = torch.randn(mean.shape, generator=generator, device=gdev, dtype=torch.float32)
         out = torch.empty_like(mean)
-        check(lib.mvoc_gaussian_sample_f16(mean.data_ptr(), logvar.data_ptr(), noise.to(self.device, H16).contiguous().data_ptr(),
-                                           out.data_ptr(), mean.numel(), ops._stream()), "gaussian_sample")
+        nz = noise.to(self.device, H16).contiguous()  # (held until the launch is enqueued)
+        check(lib.mvoc_gaussian_sample_f16(mean.data_ptr(), logvar.data_ptr(), nz.data_ptr(), out.data_ptr(), mean.numel(),
+                                           ops._stream()), "gaussian_sample")
         return out
 
     @torch.no_grad()

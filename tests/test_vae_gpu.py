@@ -156,12 +156,12 @@ def test_softmax_rows_and_small_kernels():
     mean, logvar, noise = (torch.randn(4096, generator=g).half() for _ in range(3))
     logvar[:3] = torch.tensor([-40.0, 30.0, 0.0]).half()
     out = torch.empty(4096, dtype=torch.float16, device="cuda")
-    check(lib.mvoc_gaussian_sample_f16(dev(mean).data_ptr(), dev(logvar).data_ptr(), dev(noise).data_ptr(), out.data_ptr(), 4096,
-                                       ops._stream()), "sample")
+    dm, dl, dn = dev(mean), dev(logvar), dev(noise)
+    check(lib.mvoc_gaussian_sample_f16(dm.data_ptr(), dl.data_ptr(), dn.data_ptr(), out.data_ptr(), 4096, ops._stream()), "sample")
     ref = mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise  # CPU half ops: fp32 compute, one rounding per op
     o32, r32 = out.cpu().float(), ref.float()
     assert float(((o32 - r32).abs() / r32.abs().clamp_min(1e-3)).max()) <= 1.5e-3  # at most an fp16 ulp (expf vs torch.exp)
     assert float((o32 != r32).float().mean()) < 0.02
     sc = torch.empty(4096, dtype=torch.float16, device="cuda")
-    check(lib.mvoc_scale_f16(dev(mean).data_ptr(), sc.data_ptr(), 4096, 0.18215, ops._stream()), "scale")
+    check(lib.mvoc_scale_f16(dm.data_ptr(), sc.data_ptr(), 4096, 0.18215, ops._stream()), "scale")
     assert torch.equal(sc.cpu(), mean * 0.18215)
