@@ -241,6 +241,18 @@ int mvoc_image_to_tokens_f16(const void* x, void* out, int32_t n, int32_t c, int
 int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int32_t c, int32_t hw, int32_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Mask preprocessing on the device (reference i2vgen-xl/utils.py:92-154): after PNG decode + convert("L") on the
+ * host, PIL's `mask.resize((W//8, H//8))` (BICUBIC, the 8-bit fixed-point path: 22 fractional bits, horizontal pass rounded to
+ * uint8, then vertical) reproduced bit for bit from host-built coefficient tables (per output index {xmin, n} and n int32
+ * weights, row pitch ksize), then float = v/255 in fp16 and bool = v > 10 (cv.threshold(.., 10, 255) / 255 -> bool).
+ *   in [n][H][W] u8, tmp [n][H][w] u8, out [n][h][w] u8;  float_mask fp16 / bool_mask u8 of the same element count
+ * ------------------------------------------------------------------------------------------- */
+int mvoc_mask_resize_u8(const void* in, void* tmp, void* out, int32_t n, int32_t H, int32_t W, int32_t h, int32_t w,
+                        const int32_t* bounds_h, const int32_t* kk_h, int32_t ksize_h, const int32_t* bounds_v,
+                        const int32_t* kk_v, int32_t ksize_v, void* stream);
+int mvoc_mask_finish(const void* v, void* float_mask, void* bool_mask, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * RCCL exchanges of the frame-axis shard (SURVEY 8b `allgather_frames`, 8e / BASELINE configs[3]: one long clip over the GPUs
  * of a node; the reference has no collective -- this is new work north_star asks for).  One process per GPU; rank 0 makes a
  * 128-byte id (mvoc_comm_unique_id), the host distributes it by any means, every rank calls mvoc_comm_init.  The exchanges

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mvoc_scale_f16": (i32, [vp, vp, i64, f64, vp]),
     "mvoc_image_to_tokens_f16": (i32, [vp, vp, i32, i32, i32, vp]),
     "mvoc_tokens_to_image_f16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "mvoc_mask_resize_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
+    "mvoc_mask_finish": (i32, [vp, vp, vp, i64, vp]),
     "mvoc_permute_rows_f16": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), i32, vp]),
     "mvoc_comm_unique_id": (i32, [vp]),
     "mvoc_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),

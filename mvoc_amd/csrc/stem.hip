@@ -342,6 +342,60 @@ extern "C" int mvoc_tokens_to_image_f16(const void* x, void* out, int32_t n, int
   return mvoc_check_launch("tokens_to_image_kernel");
 }
 
+// ---- mask preprocessing on the device (reference utils.py:92-154) ----------------------------------------
+// PIL's Image.resize (BICUBIC, 8-bit path) is integer arithmetic once its coefficient tables exist: per output index a window
+// [xmin, xmin+n) and n fixed-point weights (22 fractional bits); acc = 2^21 + sum(pixel * w); out = clip8(acc >> 22).  The
+// horizontal pass runs first and is itself rounded to uint8, then the vertical pass.  One thread per output pixel of a pass.
+// in [n][len_o][len_i] (ALONG = innermost) or [n][len_i][len_o] viewed through (stride_i, stride_o).
+__global__ void resize8_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int* __restrict__ bounds,
+                                    const int* __restrict__ kk, int ksize, long nimg, int olen, int other, long in_img, long out_img,
+                                    long in_si, long in_so, long out_si, long out_so) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * olen * other) return;
+  const int xx = (int)(i % olen);
+  const long t = i / olen;
+  const int o = (int)(t % other);
+  const long img = t / other;
+  const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+  const uint8_t* src = in + img * in_img + (long)o * in_so + (long)xmin * in_si;
+  int acc = 1 << 21;
+  for (int x = 0; x < n; ++x) acc += (int)src[(long)x * in_si] * kk[xx * ksize + x];
+  acc >>= 22;
+  out[img * out_img + (long)o * out_so + (long)xx * out_si] = (uint8_t)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+}
+// float mask = v / 255 (fp32 division, one rounding to fp16: `.to(float32).div_(255.0).to(dtype)`), bool mask = v > 10
+// (cv.threshold(v, 10, 255, THRESH_BINARY) -> {0, 255} -> / 255 -> bool)
+__global__ void mask_finish_kernel(const uint8_t* __restrict__ v, half_t* __restrict__ fl, uint8_t* __restrict__ bl, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = v[i];
+  fl[i] = (half_t)((float)x / 255.0f);
+  bl[i] = x > 10 ? 1 : 0;
+}
+
+extern "C" int mvoc_mask_resize_u8(const void* in, void* tmp, void* out, int32_t n, int32_t H, int32_t W, int32_t h, int32_t w,
+                                   const int32_t* bounds_h, const int32_t* kk_h, int32_t ksize_h, const int32_t* bounds_v,
+                                   const int32_t* kk_v, int32_t ksize_v, void* stream) {
+  MVOC_REQUIRE(in && tmp && out && bounds_h && kk_h && bounds_v && kk_v && n > 0 && H > 0 && W > 0 && h > 0 && w > 0, -1, "mask_resize: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, (double)n * H * W + 2.0 * n * H * w + (double)n * h * w);
+  // horizontal: [n][H][W] -> tmp [n][H][w]
+  hipLaunchKernelGGL(resize8_pass_kernel, dim3(nblk((long)n * H * w)), dim3(256), 0, s, (const uint8_t*)in, (uint8_t*)tmp, bounds_h, kk_h,
+                     ksize_h, (long)n, w, H, (long)H * W, (long)H * w, 1L, (long)W, 1L, (long)w);
+  // vertical: tmp [n][H][w] -> out [n][h][w]
+  hipLaunchKernelGGL(resize8_pass_kernel, dim3(nblk((long)n * h * w)), dim3(256), 0, s, (const uint8_t*)tmp, (uint8_t*)out, bounds_v, kk_v,
+                     ksize_v, (long)n, h, w, (long)H * w, (long)h * w, (long)w, 1L, (long)w, 1L);
+  return mvoc_check_launch("resize8_pass_kernel");
+}
+
+extern "C" int mvoc_mask_finish(const void* v, void* float_mask, void* bool_mask, int64_t n, void* stream) {
+  MVOC_REQUIRE(v && float_mask && bool_mask && n > 0, -1, "mask_finish: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * n);
+  hipLaunchKernelGGL(mask_finish_kernel, dim3(nblk(n)), dim3(256), 0, s, (const uint8_t*)v, (half_t*)float_mask, (uint8_t*)bool_mask, (long)n);
+  return mvoc_check_launch("mask_finish_kernel");
+}
+
 // row permutation copy (frame shard <-> pixel shard packing around the RCCL exchanges): out rows are contiguous over the index
 // (i0,i1,i2,i3); the source row of each is i0*s0 + i1*s1 + i2*s2 + i3*s3; thread = 16-byte chunk of a row
 __global__ void permute_rows_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int d1, int d2, int d3, long s0, long s1,

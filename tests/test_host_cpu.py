@@ -234,3 +234,18 @@ def test_mask_preprocess_matches_g9(golden_dir, tmp_path):
     fl, bl = mask_preprocess(one, "cpu", torch.float16, 1, 4, 5, downscale=8)
     assert tuple(fl.shape) == (1, 4, 5, 90, 160) and all(torch.equal(fl[0, 0, 0], fl[0, 0, k]) for k in range(5))
     assert torch.equal(bl[0, 0, 0], torch.from_numpy(g["boat_mask_90x160_bool"][3]))
+
+
+def test_pil_bicubic_tables_reproduce_pil(golden_dir):
+    """the coefficient tables the device mask preprocessing uses (mvoc_amd.utils.pil_bicubic_tables) evaluated with numpy
+    equal Pillow's own Image.resize bit for bit: /8 downscale of the demo masks, a non-integer ratio, an upscale"""
+    import numpy as np
+    from PIL import Image
+    from mvoc_amd.utils import resize8_reference
+    for name, i in (("boat_mask", 0), ("surf_mask", 9)):
+        im = Image.open(os.path.join(golden_dir, "boat_surf_masks", name, f"{i:05d}.png")).convert("L")
+        W, H = im.size
+        for size in ((W // 8, H // 8), (100, 57), (1500, 900)):
+            ref = np.asarray(im.resize(size))
+            got = resize8_reference(np.asarray(im), (size[1], size[0]))
+            assert np.array_equal(ref, got), (name, size)

@@ -165,3 +165,21 @@ def test_softmax_rows_and_small_kernels():
     sc = torch.empty(4096, dtype=torch.float16, device="cuda")
     check(lib.mvoc_scale_f16(dm.data_ptr(), sc.data_ptr(), 4096, 0.18215, ops._stream()), "scale")
     assert torch.equal(sc.cpu(), mean * 0.18215)
+
+
+def test_mask_preprocess_on_device_matches_g9(golden_dir):
+    """mask preprocessing with the resize / threshold / scaling on the GPU (PNG decode on the host) against G9 =
+    the reference's own mask_preprocess output on the boat_surf masks -- bit for bit, float and bool"""
+    import os
+    from mvoc_amd.utils import mask_preprocess
+    g = np.load(os.path.join(golden_dir, "g9_boat_surf_masks.npz"))
+    for name in ("boat_mask", "surf_mask"):
+        fl, bl = mask_preprocess(os.path.join(golden_dir, "boat_surf_masks", name), "cuda:0", torch.float16, 1, 4, 16, downscale=8)
+        assert fl.is_cuda and fl.dtype == torch.float16 and bl.dtype == torch.bool and tuple(fl.shape) == (1, 4, 16, 90, 160)
+        want = (torch.from_numpy(g[f"{name}_90x160_float_u8"]).float() / 255).half()
+        for c in range(4):
+            assert torch.equal(fl[0, c].cpu(), want)
+            assert torch.equal(bl[0, c].cpu(), torch.from_numpy(g[f"{name}_90x160_bool"]))
+    one = os.path.join(golden_dir, "boat_surf_masks", "surf_mask", "00002.png")
+    fl, bl = mask_preprocess(one, "cuda:0", torch.float16, 1, 4, 3, downscale=8)
+    assert tuple(fl.shape) == (1, 4, 3, 90, 160) and torch.equal(bl[0, 0, 1].cpu(), torch.from_numpy(g["surf_mask_90x160_bool"][2]))
