@@ -110,6 +110,25 @@ typedef struct mvoc_tattn_desc {
 } mvoc_tattn_desc;
 int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream);
 
+/* Fused front half of a temporal self-attention at the finest level: LayerNorm -> to_q/to_k/to_v -> attention over the frame
+ * axis, Q/K/V never written to HBM (TransformerTemporalModel's attn1 / attn2: pnp_utils.py:170-220, 222-346, 720-887; replaces
+ * mvoc_row_stats_f16 + the fused-QKV mvoc_gemm_f16 + mvoc_temporal_attn_f16 where no PnP Q/K injection is scheduled).
+ *   x   [nsample*frames*hw][c] raw rows of the canonical layout (c = heads*64 in {64, 128, 320}, frames in {8, 16, 32})
+ *   wp  the gamma-scaled [3c][c] projection W' = cat(Wq, Wk, Wv) * gamma re-ordered in MFMA fragment order:
+ *       [head][tile: q0 q1 k0 k1 v0 v1][k16 step s < c/16][lane < 64][8 fp16], element = W'[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]
+ *       with row0 = {0, c, 2c}[tile / 2] + 64 head + 32 (tile & 1)   (mvoc_amd.unet.pack_tfused_weights)
+ *   ln_rowsum / ln_bias fp32 [3c] as for the folded GEMM; out [rows][c] = heads concatenated, before to_out */
+typedef struct mvoc_tfused_desc {
+  const void* x;
+  const void* wp;
+  const void* ln_rowsum;
+  const void* ln_bias;
+  void* out;
+  int32_t nsample, frames, hw, c, heads;
+  float ln_eps;
+} mvoc_tfused_desc;
+int mvoc_temporal_qkv_attn_f16(const mvoc_tfused_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU) on channels-last rows; F.group_norm + F.silu at pnp_utils.py:909-910, 953-965 (4-D,
  * statistics per image), :188 and TemporalConvLayer (5-D, statistics per video), :430, and

@@ -51,6 +51,11 @@ class GnDesc(C.Structure):
                 ("groups", i32), ("silu", i32), ("eps", f32)]
 
 
+class TFusedDesc(C.Structure):
+    _fields_ = [("x", vp), ("wp", vp), ("ln_rowsum", vp), ("ln_bias", vp), ("out", vp), ("nsample", i32), ("frames", i32),
+                ("hw", i32), ("c", i32), ("heads", i32), ("ln_eps", f32)]
+
+
 class PnpDesc(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("masks", vp), ("chunk_stride", i64), ("f_stride", i64), ("p_stride", i64),
                 ("nobj", i32), ("frames", i32), ("height", i32), ("width", i32), ("channels", i32), ("mask_h", i32),
@@ -65,6 +70,7 @@ SIGNATURES = {
     "mvoc_gemm_workspace_bytes": (sz, [i64, i64, i64]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
+    "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
     "mvoc_groupnorm_moments_f16": (i32, [C.POINTER(GnDesc), vp, vp]),

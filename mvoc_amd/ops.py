@@ -9,7 +9,7 @@ import torch
 
 from . import _ffi
 from ._ffi import (A_CONV3X3, A_PLAIN, A_TEMPORAL3, ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc, GnDesc,
-                   PnpDesc, TAttnDesc, check, lib)
+                   PnpDesc, TAttnDesc, TFusedDesc, check, lib)
 
 __all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "groupnorm_moments", "groupnorm_apply_moments", "layernorm", "pnp_blend_tokens",
            "pnp_blend_nchw", "ddim_step", "latent_fusion", "timestep_embedding", "act", "add", "conv3x3_small",
@@ -181,6 +181,28 @@ def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
         setattr(d, name + "_bs", frames * hw * ld)
     d.nsample, d.hw, d.heads, d.frames = nsample, hw, heads, frames
     check(lib.mvoc_temporal_attn_f16(C.byref(d), _stream()), "temporal_attn")
+    return out
+
+
+TFUSED_CHANNELS = (64, 128, 320)
+TFUSED_FRAMES = (8, 16, 32)
+
+
+def temporal_qkv_attn(x, wp, ln, *, nsample, frames, hw, heads, out=None):
+    """LayerNorm -> QKV -> attention over the frame axis in one kernel (see include/mvoc_hip.h): x raw rows
+    [nsample*frames*hw, c], wp the fragment-packed gamma-scaled QKV weights, ln = (rowsum fp32 [3c], bias fp32 [3c], eps)."""
+    _chk(x, "x"), _chk(wp, "wp"), _chk(ln[0], "ln rowsum", torch.float32), _chk(ln[1], "ln bias", torch.float32)
+    c = heads * 64
+    if not x.is_contiguous() or tuple(x.shape) != (nsample * frames * hw, c):
+        raise RuntimeError(f"temporal_qkv_attn: x must be contiguous [{nsample * frames * hw}, {c}], got {tuple(x.shape)}")
+    if wp.numel() != 3 * c * c or ln[0].numel() != 3 * c or ln[1].numel() != 3 * c:
+        raise RuntimeError("temporal_qkv_attn: packed weights / LayerNorm vectors do not match c")
+    if out is None:
+        out = torch.empty_like(x)
+    d = TFusedDesc()
+    d.x, d.wp, d.ln_rowsum, d.ln_bias, d.out = x.data_ptr(), wp.data_ptr(), ln[0].data_ptr(), ln[1].data_ptr(), out.data_ptr()
+    d.nsample, d.frames, d.hw, d.c, d.heads, d.ln_eps = nsample, frames, hw, c, heads, ln[2]
+    check(lib.mvoc_temporal_qkv_attn_f16(C.byref(d), _stream()), "temporal_qkv_attn")
     return out
 
 

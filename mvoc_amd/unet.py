@@ -75,6 +75,21 @@ def pack_geglu(w, b):
     return w[src].contiguous(), b[src].contiguous()
 
 
+def pack_tfused_weights(wqkv, heads):
+    """[3C, C] gamma-scaled QKV weights -> MFMA fragment order for mvoc_temporal_qkv_attn_f16:
+    [head][tile q0 q1 k0 k1 v0 v1][k16 step][lane][8], element = W[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
+    c = wqkv.shape[1]
+    assert wqkv.shape[0] == 3 * c and c == heads * 64
+    rows = []
+    for hd in range(heads):
+        for t in range(6):
+            row0 = (t // 2) * c + hd * 64 + (t % 2) * 32
+            rows.append(wqkv[row0:row0 + 32])
+    w = torch.stack(rows)                                   # [heads*6, 32 rows, C]
+    w = w.view(heads * 6, 32, c // 16, 2, 8)                # row r, k16 step s, half h, 8 elements
+    return w.permute(0, 2, 3, 1, 4).contiguous()            # [tile, s, h, r, 8]: lane = 32 h + r
+
+
 class Hookable:
     """carrier of the reference's per-site hook state"""
 
@@ -148,6 +163,13 @@ class Attention:
             self.to_qkv = Linear(torch.cat([g(".to_q.weight"), g(".to_k.weight"), g(".to_v.weight")], 0))
         self.to_out = Linear(g(".to_out.0.weight"), g(".to_out.0.bias"))
         self.inner = g(".to_q.weight").shape[0]
+        self.tfused = None  # fragment-packed folded QKV weights of a temporal self-attention (TransformerTemporalModel)
+
+    def pack_tfused(self):
+        """after the LayerNorm has been folded into to_qkv: the weights in the fused temporal kernel's order"""
+        q = self.to_qkv
+        if not self.cross and q.ln is not None and self.inner in ops.TFUSED_CHANNELS and q.w_ln.shape == (3 * self.inner, self.inner):
+            self.tfused = pack_tfused_weights(q.w_ln, self.heads)
 
 
 class BasicTransformerBlock:
@@ -223,8 +245,14 @@ class TransformerTemporalModel(_TransformerBase):
     """``pnp_utils.py:170-220`` (+ ``:720-887``): 5-D GroupNorm (statistics over frames too), then a transformer
     block whose two attentions both run over the frame axis of each pixel."""
 
+    use_fused = True  # LN -> QKV -> frame attention in one kernel where the shape allows it (C in {64,128,320}, F in {8,16,32})
+
     def __init__(self, sd, prefix, cin, heads, groups):
         super().__init__(sd, prefix, cin, heads, groups, False)
+        blk = self.transformer_blocks[0]
+        if blk.dim == heads * 64:
+            blk.attn1.pack_tfused()
+            blk.attn2.pack_tfused()
 
     def forward(self, eng, x, geo):
         return eng.temporal_section(x, geo, self._section)
@@ -239,10 +267,16 @@ class TransformerTemporalModel(_TransformerBase):
         h = self.proj_in(h)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
+            proc = attn.processor
+            inject = attn is blk.attn1 and proc.injecting()
+            if self.use_fused and attn.tfused is not None and not inject and F in ops.TFUSED_FRAMES and h.is_contiguous():
+                # Q/K/V never leave the chip: LayerNorm, projection and the frame attention of 32/F pixels per wave in one kernel
+                a = ops.temporal_qkv_attn(h, attn.tfused, attn.to_qkv.ln, nsample=B, frames=F, hw=hw, heads=self.heads)
+                h = attn.to_out(a, resid=h)
+                continue
             qkv = attn.to_qkv.call_ln(h, norm)
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
-            proc = attn.processor
-            if attn is blk.attn1 and proc.injecting():
+            if inject:
                 ndst = eng.check_pnp_batch(B, proc.mask)
                 masks = eng.section_masks(proc.mask, 0, full_hw)  # soft float masks, channel 0
                 ld = qkv.stride(0)

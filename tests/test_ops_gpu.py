@@ -434,6 +434,37 @@ def test_temporal_attn(ops, frames, heads):
     assert (out.float().cpu() - ref).abs().max() < 1e-2
 
 
+@pytest.mark.parametrize("c,frames,hw,ns", [(64, 16, 21, 2), (128, 8, 40, 3), (320, 16, 70, 2), (320, 32, 9, 1), (320, 8, 33, 2),
+                                            (320, 16, 1024, 1)])
+def test_temporal_qkv_attn_fused(ops, c, frames, hw, ns):
+    """LayerNorm -> QKV -> attention over frames in one kernel (Q/K/V never in HBM) against torch (F.layer_norm, F.linear, SDPA
+    per pixel over the frame axis) and against the unfused kernel chain; ragged pixel counts exercise the dead-pixel lanes"""
+    from mvoc_amd.unet import Linear, pack_tfused_weights
+    heads = c // 64
+    g = torch.Generator().manual_seed(c + frames + hw)
+    rows = ns * frames * hw
+    x = (torch.randn(rows, c, generator=g) * 1.4 + 0.3).half()
+    w = (torch.randn(3 * c, c, generator=g) / math.sqrt(c)).half()
+    gm, bt = (1 + 0.3 * torch.randn(c, generator=g)).half(), (0.3 * torch.randn(c, generator=g)).half()
+    lin = Linear(dev(w)).fold_layernorm(dev(gm), dev(bt))
+    wp = pack_tfused_weights(lin.w_ln, heads)
+    out = ops.temporal_qkv_attn(dev(x), wp, lin.ln, nsample=ns, frames=frames, hw=hw, heads=heads)
+    # torch reference with the reference's fp16 rounding of q/k/v
+    qkv = (F.layer_norm(x.float(), (c,), gm.float(), bt.float(), 1e-5).half().float() @ w.float().t()).half().float()
+
+    def seq(t):  # [ns, F, hw, heads, 64] -> [ns*hw, heads, F, 64]
+        return t.reshape(ns, frames, hw, heads, 64).permute(0, 2, 3, 1, 4).reshape(ns * hw, heads, frames, 64)
+
+    ref = F.scaled_dot_product_attention(seq(qkv[:, :c]), seq(qkv[:, c:2 * c]), seq(qkv[:, 2 * c:]))
+    ref = ref.reshape(ns, hw, heads, frames, 64).permute(0, 3, 1, 2, 4).reshape(rows, c)
+    assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)
+    assert (out.float().cpu() - ref).abs().max() < 2e-2
+    # the unfused chain of this library (row statistics + folded GEMM + temporal attention kernel)
+    q3 = lin.call_ln(dev(x), (dev(gm), dev(bt)))
+    un = ops.temporal_attn(q3[:, :c], q3[:, c:2 * c], q3[:, 2 * c:], nsample=ns, frames=frames, hw=hw, heads=heads)
+    assert rel_l2(out, un) < 2e-3
+
+
 # ---- norms ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,groups,rows,nsample,silu", [(320, 32, 64, 5, True), (64, 8, 37, 3, False), (2560, 32, 16, 2, True),
                                                         (960, 32, 100, 4, True), (128, 8, 4096, 2, False)])

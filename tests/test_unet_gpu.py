@@ -89,7 +89,8 @@ def test_g7_pnp_against_reference_golden(golden_dir):
             assert torch.equal(out[3], out[4])
 
 
-@pytest.mark.parametrize("b,f,h,w,mfg", [(1, 3, 8, 8, False), (2, 2, 10, 6, False), (1, 5, 12, 9, True)])
+@pytest.mark.parametrize("b,f,h,w,mfg", [(1, 3, 8, 8, False), (2, 2, 10, 6, False), (1, 5, 12, 9, True), (1, 8, 8, 8, False),
+                                         (2, 16, 10, 6, False)])
 def test_forward_vs_oracle_shapes(pair, b, f, h, w, mfg):
     """odd latent sizes exercise the forced upsample-size path (pipeline_i2vgen_xl.py:156-164, 328-329)"""
     o, eng = pair
@@ -104,6 +105,34 @@ def test_forward_vs_oracle_shapes(pair, b, f, h, w, mfg):
     ref = o.forward_ext(sample, 501, fps, il1, il, ie, eh, multi_frame_guidance=mfg)[0]
     out = eng.forward_ext(sample, 501, fps, il1, il, ie, eh, multi_frame_guidance=mfg)[0]
     _close(out, ref, f"ext {b,f,h,w,mfg}")
+
+
+def test_fused_temporal_attention_is_used_and_agrees(pair):
+    """F in {8,16,32}: the temporal transformers run LN -> QKV -> frame attention as one kernel; same network with the
+    unfused chain must agree to fp16 noise, and a PnP-injecting attn1 must fall back (the blend needs Q/K in memory)"""
+    from mvoc_amd.unet import TransformerTemporalModel
+    from mvoc_amd import ops
+    o, eng = pair
+    g = torch.Generator().manual_seed(77)
+    b, f, h, w = 1, 8, 8, 8
+    cd = o.config.cross_attention_dim
+    r = lambda *s_: torch.randn(*s_, generator=g).half().float()
+    args = (r(b, 4, f, h, w), 301, torch.tensor([8] * b), r(b, 4, f, h, w), r(b, 4, f, h, w), r(b, f, cd), r(b, 7, cd))
+    calls = []
+    real = ops.temporal_qkv_attn
+    ops.temporal_qkv_attn = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        fused = eng.forward_ext(*args)[0]
+    finally:
+        ops.temporal_qkv_attn = real
+    assert len(calls) >= 2 * 16  # 17 temporal transformers, two attentions each (transformer_in has its own width)
+    TransformerTemporalModel.use_fused = False
+    try:
+        unfused = eng.forward_ext(*args)[0]
+    finally:
+        TransformerTemporalModel.use_fused = True
+    rel = float((fused.float() - unfused.float()).norm() / unfused.float().norm())
+    assert rel < 2e-3, rel
 
 
 def test_stock_forward_vs_oracle(pair):
