@@ -115,8 +115,8 @@ int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream);
  * mvoc_row_stats_f16 + the fused-QKV mvoc_gemm_f16 + mvoc_temporal_attn_f16 where no PnP Q/K injection is scheduled).
  *   x   [nsample*frames*hw][c] raw rows of the canonical layout (c = heads*64 in {64, 128, 320}, frames in {8, 16, 32})
  *   wp  the gamma-scaled [3c][c] projection W' = cat(Wq, Wk, Wv) * gamma re-ordered in MFMA fragment order:
- *       [head][tile: q0 q1 k0 k1 v0 v1][k16 step s < c/16][lane < 64][8 fp16], element = W'[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]
- *       with row0 = {0, c, 2c}[tile / 2] + 64 head + 32 (tile & 1)   (mvoc_amd.unet.pack_tfused_weights)
+ *       [head][tile: q0 k0 q1 k1 v0 v1][k16 step s < c/16][lane < 64][8 fp16], element = W'[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]
+ *       with row0 = 64 head + {0, c, 32, c + 32, 2c, 2c + 32}[tile]   (mvoc_amd.unet.pack_tfused_weights)
  *   ln_rowsum / ln_bias fp32 [3c] as for the folded GEMM; out [rows][c] = heads concatenated, before to_out */
 typedef struct mvoc_tfused_desc {
   const void* x;

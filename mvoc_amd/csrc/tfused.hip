@@ -10,14 +10,16 @@
 // only the (gamma-scaled) weights stream, pre-packed on the host in fragment order so that every LDS-DMA piece is 1 KB
 // contiguous in memory and every fragment read is 1 KB contiguous in LDS (no swizzle, no bank conflict).  Per staged weight
 // byte the block does 256 flop (the activation operand is never staged), against 128-142 for the best GEMM tile.
-//   per head:  q, k tiles  D[ch][row]  = W'  x^T   (weights as the row operand)        4 stages of 32 weight rows
+//   per head:  q, k tiles  D[ch][row]  = W'  x^T   (weights as the row operand)        4 stages of 32 weight rows (q0 k0 q1 k1)
 //              S^T = K Q^T  from the fp16-packed accumulators (both carry the same channel permutation)
 //              block-diagonal softmax (a row attends only to the rows of its own pixel), P^T packed
 //              v tiles     D[row][d]   = x  W'^T   (activations as the row operand)    2 stages
 //              O^T = V^T P^T, scaled by 1/rowsum, stored as 8-byte channel quads
-//   LayerNorm is folded: the MFMAs run on raw rows, the per-row mean / rstd come from the register fragments (one shuffle),
-//   and the accumulators are fixed up as rstd * (acc - mean * rowsum(W')) + beta @ W^T before the fp16 rounding that the
+//   LayerNorm: the row's mean / rstd come from the register fragments (one shuffle) and the fragments are normalised in place,
+//   once; gamma is folded into the weights and beta into a per-channel constant added before the fp16 rounding that the
 //   reference's q / k / v tensors have.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -30,6 +32,7 @@ struct TfArgs {
   half_t* out;
   int nsample, frames, logf, hw, c, heads;
   float eps, scale_log2;
+  unsigned long long* stamps;  // diagnostic builds only
 };
 
 template <int N>
@@ -37,24 +40,34 @@ __device__ __forceinline__ void tf_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef MVOC_PP_LAB
+#define TF_STAMP(t)                                                                        \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+#else
+#define TF_STAMP(t) do { } while (0)
+#endif
+
 template <int NK>
 __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   constexpr int NS = 4;                 // weight-stage ring (one stage = 32 weight rows x C = NK KB)
   constexpr int STAGE = NK * 1024;
-  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE + 8 * 256 + 2 * 3 * NK * 16 * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE + 3 * NK * 16 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int F = p.frames, C = p.c;
+#ifdef MVOC_PP_LAB
+  unsigned long long tb = 0;
+  TF_STAMP(tb);
+#endif
   const int ppw = 32 >> p.logf;         // pixels per wave
-  float* stats = reinterpret_cast<float*>(smem + NS * STAGE + wave * 256);  // [32 rows][mean, rstd]
   // LayerNorm-fold vectors in LDS (an ordinary global load next to in-flight LDS-DMA makes hipcc drain vmcnt(0))
-  float* lns = reinterpret_cast<float*>(smem + NS * STAGE + 8 * 256);       // [3C] row sums of W'
-  float* lnc = lns + 3 * NK * 16;                                            // [3C] beta @ W^T
-  for (int i = tid; i < 3 * NK * 16; i += 512) {
-    lns[i] = p.ln_s[i];
-    lnc[i] = p.ln_c[i];
-  }
+  float* lnc = reinterpret_cast<float*>(smem + NS * STAGE);                 // [3C] beta @ W^T (+ bias)
+  for (int i = tid; i < 3 * NK * 16; i += 512) lnc[i] = p.ln_c[i];
 
   // ---- this lane's row: tile row r = (pixel r / F, frame r % F) ---------------------------------------------------------
   const int px = (int)blockIdx.x * (8 * ppw) + wave * ppw + (r >> p.logf);
@@ -76,8 +89,8 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
                                          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
     }
   };
-  auto wait_stage = [&](int st) {  // this wave's pieces of stage st have landed (later stages may stay in flight)
-    const int ahead = T - 1 - st < 2 ? T - 1 - st : 2;  // stages issued beyond st at this point
+  auto wait_stage = [&](int st, int issued_beyond) {  // this wave's pieces of stage st have landed (later stages may stay in flight)
+    const int ahead = T - 1 - st < issued_beyond ? T - 1 - st : issued_beyond;  // stages issued beyond st at this point
     const int n = ahead * pw;
     if (n >= 6) tf_wait<6>(); else if (n == 4) tf_wait<4>(); else if (n == 3) tf_wait<3>(); else if (n == 2) tf_wait<2>();
     else if (n == 1) tf_wait<1>(); else tf_wait<0>();
@@ -107,59 +120,113 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   s2 += __shfl_xor(s2, 32);
   const float mu = s1 / (float)C;
   const float rs = rsqrtf(fmaxf(s2 / (float)C - mu * mu, 0.f) + p.eps);
-  if (h == 0) {
-    stats[2 * r] = mu;
-    stats[2 * r + 1] = rs;
-  }
+  // normalise the row in place, once: x^ = (x - mean) * rstd in fp16.  gamma rides on the weights (W' = W * gamma) and beta in the
+  // per-channel constant c = beta @ W^T, so a projection tile's fix-up is ONE add per value -- no row-sum correction, no
+  // per-row statistics in the epilogues (the earlier rstd * (acc - mean * rowsum) + c form cost ~1000 cycles per stage beside
+  // the partner's MFMAs)
+#pragma unroll
+  for (int s = 0; s < NK; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)(((float)xf[s][e] - mu) * rs);
 
+  // The two waves of a SIMD (wave w and w + 4) run ONE BARRIER APART: while one multiplies a stage (20 MFMAs on registers and
+  // LDS fragments), its partner does the previous stage's LayerNorm fix-up / softmax / stores (VALU, LDS, VMEM) -- matrix pipe
+  // beside vector pipe by construction.  Two barriers per stage:
+  //     bar_M ; issue stage+3 ; MFMAs(stage) ; wait(stage+1 landed) ; bar_E ; epilogue(stage)
+  // group B (waves 4-7) executes one extra barrier up front, group A one at the end.  A stage's pieces are waited for (by every
+  // wave, counted vmcnt) before the barrier that precedes any wave's MFMAs on it; a ring slot is refilled two barriers after
+  // its last reader finished.
   int stage = 0;
-  bool waited = false;
-  // one weight stage: acc += (32 weight rows) x (this wave's 32 activation rows); w_rows: weights are the row operand
+  const int grp = wave >> 2;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+  unsigned long long s_bm = 0, s_is = 0, s_mf = 0, s_wt = 0, s_be = 0;
+  (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)s_bm; (void)s_is; (void)s_mf; (void)s_wt; (void)s_be;
+  wait_stage(0, 2);
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+#ifdef MVOC_PP_LAB
+  unsigned long long tpro = 0;
+  TF_STAMP(tpro);
+  tpro -= tb;
+#endif
+  // fragment reads run PD ahead of the MFMA that consumes them; the first PD of a stage are issued in the PREVIOUS stage's
+  // epilogue phase (the stage is known to have landed there), so an MFMA phase starts on registers
+  constexpr int PD = NK < 8 ? NK : 8;
+  half8_t wf[PD];
+  auto prefetch = [&](int st) {
+    const char* wl = smem + (st & (NS - 1)) * STAGE + lane * 16;
+#pragma unroll
+    for (int i = 0; i < PD; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 1024);
+  };
+  prefetch(0);
+  // one weight stage: acc += (32 weight rows) x (this wave's 32 activation rows); w_rows: weights are the row operand.
+  //     bar_M ; MFMAs(stage) ; wait(stage+1 landed) ; bar_E ; first reads of stage+1 ; issue stage+3   | caller: epilogue(stage)
   auto run_stage = [&](f32x16& acc, bool w_rows) {
-    if (!waited) wait_stage(stage);
-    waited = false;
-    __builtin_amdgcn_s_barrier();               // stage landed for every wave; the slot of stage-1 is free
-    if (stage + NS - 1 < T) issue(stage + NS - 1);
+    TF_STAMP(t3);
+    // stage+1 must have landed for EVERY wave before the barrier after which the partner group pre-reads it (its bar_E is this
+    // group's bar_M): pieces are issued through stage+2 at this point
+    if (stage + 1 < T) wait_stage(stage + 1, 1);
+    TF_STAMP(t0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();               // bar_M
+    __builtin_amdgcn_sched_barrier(0);
+    TF_STAMP(t1);
+#ifdef MVOC_PP_LAB
+    s_wt += t0 - t3;
+#endif
     const char* wl = smem + (stage & (NS - 1)) * STAGE + lane * 16;
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
-      const half8_t wf = *reinterpret_cast<const half8_t*>(wl + s * 1024);
-      acc = w_rows ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[s], acc, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[s], wf, acc, 0, 0, 0);
+      acc = w_rows ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PD], xf[s], acc, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[s], wf[s % PD], acc, 0, 0, 0);
+      if (s + PD < NK) wf[s % PD] = *reinterpret_cast<const half8_t*>(wl + (s + PD) * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
     }
     ++stage;
+    TF_STAMP(t4);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();               // bar_E: the partner group starts its MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    TF_STAMP(t5);
+    if (stage < T) prefetch(stage);             // (landed: waited for by every wave before the previous barrier)
+    // the slot of the stage before the one just multiplied is free: the partner multiplied it one barrier interval ago
+    if (stage + NS - 2 < T) issue(stage + NS - 2);
+    TF_STAMP(t2);
+#ifdef MVOC_PP_LAB
+    s_bm += t1 - t0; s_mf += t4 - t1; s_be += t5 - t4; s_is += t2 - t5;
+#endif
+  };
+
+  // a q or k tile: D[channel][row] = W' x^T, LayerNorm fix-up, fp16 -> the two k16 operand fragments of the 32 channels
+  auto proj_qk = [&](int nbase, half8_t (&pk)[2]) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    run_stage(acc, true);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nbase + 8 * q + 4 * h;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(lnc + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[q >> 1][4 * (q & 1) + e] = (half_t)(acc[4 * q + e] + cv[e]);
+    }
   };
 
   for (int hd = 0; hd < p.heads; ++hd) {
-    // ---- q, k : D[channel][row] ------------------------------------------------------------------------------------------
-    half8_t qp[2][2], kp[2][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      run_stage(acc, true);
-      const int nbase = (t >> 1) * C + hd * 64 + (t & 1) * 32;  // q rows, then k rows of the [3C] projection
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = nbase + 8 * q + 4 * h;
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(lns + n);
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(lnc + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const half_t v = (half_t)(rs * (acc[4 * q + e] - mu * sv[e]) + cv[e]);
-          if (t < 2) qp[t & 1][q >> 1][4 * (q & 1) + e] = v; else kp[t & 1][q >> 1][4 * (q & 1) + e] = v;
-        }
-      }
-    }
-    // ---- S^T = K Q^T, block-diagonal softmax ------------------------------------------------------------------------------
+    // ---- S^T = K Q^T over the head's 64 channels, 32 at a time (stage order q0 k0 q1 k1) -----------------------------------
     f32x16 st;
 #pragma unroll
     for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      half8_t qp[2], kp[2];
+      proj_qk(hd * 64 + 32 * i, qp);
+      proj_qk(C + hd * 64 + 32 * i, kp);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kp[i][s], qp[i][s], st, 0, 0, 0);
+      for (int s = 0; s < 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kp[s], qp[s], st, 0, 0, 0);
+    }
+    // ---- block-diagonal softmax: a row attends only to the rows of its own pixel ------------------------------------------
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -183,8 +250,7 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pp[s][j] = (half_t)st[8 * s + j];
-    // ---- v : D[row][d], then O^T = V^T P^T ----------------------------------------------------------------------------------
-    f32x16 ot[2];
+    // ---- v : D[row][d] = x W'^T, then O^T = V^T P^T, 32 value channels at a time ---------------------------------------------
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       f32x16 acc;
@@ -192,34 +258,53 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       run_stage(acc, false);
       const int n = 2 * C + hd * 64 + dt * 32 + r;  // this lane's value channel
-      const float sv = lns[n], cv = lnc[n];
+      const float cv = lnc[n];
       half8_t vp[2];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = 8 * (e >> 2) + 4 * h + (e & 3);
-        const float m_ = stats[2 * row], r_ = stats[2 * row + 1];
-        vp[e >> 3][e & 7] = (half_t)(r_ * (acc[e] - m_ * sv) + cv);
-      }
+      for (int e = 0; e < 16; ++e) vp[e >> 3][e & 7] = (half_t)(acc[e] + cv);
+      f32x16 ot;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+      for (int e = 0; e < 16; ++e) ot[e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vp[s], pp[s], ot[dt], 0, 0, 0);
-    }
-    // retire the next stage's pieces BEFORE the stores enter the in-order vmcnt queue behind them
-    if (stage < T) { wait_stage(stage); waited = true; }
-    if (live) {
-      half_t* op = p.out + grow * C + hd * 64;
+      for (int s = 0; s < 2; ++s) ot = __builtin_amdgcn_mfma_f32_32x32x16_f16(vp[s], pp[s], ot, 0, 0, 0);
+      // In the accumulator layout a lane owns 4 consecutive channels (8 B) of its row per quad, the row's other 4 sit in lane
+      // +-32: v_permlane32_swap pairs quads (0,1) and (2,3) so that each lane ends up with 8 consecutive channels -> two 16-byte
+      // stores per tile instead of four 8-byte ones (the 8-byte row-strided stores were issue-bound: half the per-head time)
+      unsigned pk[4][2];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][q * 4 + e] * inv);
-          *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h) = o;
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const half2_t v2 = {(half_t)(ot[q * 4 + 2 * w2] * inv), (half_t)(ot[q * 4 + 2 * w2 + 1] * inv)};
+          pk[q][w2] = __builtin_bit_cast(unsigned, v2);
         }
+#pragma unroll
+      for (int qq = 0; qq < 4; qq += 2)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 1][w2], false, false);
+          pk[qq][w2] = sw[0];       // lanes < 32: quad qq of this lane     | lanes >= 32: quad qq+1 of lane - 32
+          pk[qq + 1][w2] = sw[1];   // lanes < 32: quad qq of lane + 32     | lanes >= 32: quad qq+1 of this lane
+        }
+      if (live) {
+        // lane (r, h) now holds channels 16 j + 8 h + {0..7} of row r for j = 0, 1
+        half_t* op = p.out + grow * C + hd * 64 + 32 * dt + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 v = {pk[2 * j][0], pk[2 * j][1], pk[2 * j + 1][0], pk[2 * j + 1][1]};
+          *reinterpret_cast<uint4*>(op + 16 * j) = v;
+        }
+      }
     }
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // group A's balancing barrier
+#ifdef MVOC_PP_LAB
+  TF_STAMP(t0);
+  if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4) && lane == 0) {
+    unsigned long long* o = p.stamps + (wave >> 2) * 8;
+    o[0] = s_bm; o[1] = s_is; o[2] = s_mf; o[3] = s_wt; o[4] = s_be; o[5] = (t0 - tb) - (s_bm + s_is + s_mf + s_wt + s_be) - tpro; o[6] = tpro; o[7] = t0 - tb;
+  }
+#endif
 }
 
 }  // namespace
@@ -237,6 +322,10 @@ extern "C" int mvoc_temporal_qkv_attn_f16(const mvoc_tfused_desc* d, void* strea
   a.logf = d->frames == 8 ? 3 : d->frames == 16 ? 4 : 5;
   a.eps = d->ln_eps;
   a.scale_log2 = 0.125f * 1.4426950408889634f;
+  a.stamps = nullptr;
+#ifdef MVOC_PP_LAB
+  if (const char* e = getenv("MVOC_TF_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 10);
+#endif
   const int ppb = 8 * (32 / d->frames);  // pixels per block
   dim3 grid((unsigned)((d->hw + ppb - 1) / ppb), (unsigned)d->nsample);
   hipStream_t s = (hipStream_t)stream;

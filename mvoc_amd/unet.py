@@ -77,13 +77,13 @@ def pack_geglu(w, b):
 
 def pack_tfused_weights(wqkv, heads):
     """[3C, C] gamma-scaled QKV weights -> MFMA fragment order for mvoc_temporal_qkv_attn_f16:
-    [head][tile q0 q1 k0 k1 v0 v1][k16 step][lane][8], element = W[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
+    [head][tile q0 k0 q1 k1 v0 v1][k16 step][lane][8], element = W[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
     c = wqkv.shape[1]
     assert wqkv.shape[0] == 3 * c and c == heads * 64
     rows = []
     for hd in range(heads):
-        for t in range(6):
-            row0 = (t // 2) * c + hd * 64 + (t % 2) * 32
+        for off in (0, c, 32, c + 32, 2 * c, 2 * c + 32):
+            row0 = hd * 64 + off
             rows.append(wqkv[row0:row0 + 32])
     w = torch.stack(rows)                                   # [heads*6, 32 rows, C]
     w = w.view(heads * 6, 32, c // 16, 2, 8)                # row r, k16 step s, half h, 8 elements

@@ -44,3 +44,17 @@ for ns, frames, hw in ((1, 16, 4096), (5, 16, 4096), (1, 32, 9216)):
     tu, tf = timed(unfused), timed(fused)
     print(f"B={ns} F={frames} hw={hw}: unfused (row_stats + QKV GEMM + tattn) {tu:8.1f} us = {fl / tu / 1e6:6.0f} TF/s | "
           f"fused {tf:8.1f} us = {fl / tf / 1e6:6.0f} TF/s = {100 * fl / tf / 1e6 / 2500:4.1f} % of 2.5 PF | x{tu / tf:.2f}", flush=True)
+
+import os
+if "lab" in os.environ.get("MVOC_HIP_LIB", ""):
+    st = torch.zeros(16, dtype=torch.int64, device="cuda")
+    os.environ["MVOC_TF_STAMPS"] = str(st.data_ptr())
+    ns, frames, hw = 5, 16, 4096
+    x = torch.randn(ns * frames * hw, c, generator=g, device="cuda").half()
+    ops.temporal_qkv_attn(x, wp, lin.ln, nsample=ns, frames=frames, hw=hw, heads=heads)
+    torch.cuda.synchronize()
+    v = st.cpu().tolist()
+    names = ["bar_M", "issue", "mfma", "vmwait", "bar_E", "epilogues", "prologue"]
+    for grp in range(2):
+        tot = max(v[grp * 8 + 7], 1)
+        print(f"group {'AB'[grp]}: " + "  ".join(f"{n} {100.0 * v[grp * 8 + i] / tot:4.1f}%" for i, n in enumerate(names)) + f" | total {tot} cycles, {tot / 30:.0f} per stage")
