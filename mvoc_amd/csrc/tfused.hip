@@ -51,9 +51,13 @@ __device__ __forceinline__ void tf_wait() {
 #define TF_STAMP(t) do { } while (0)
 #endif
 
-template <int NK>
-__global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
-  constexpr int NS = 4;                 // weight-stage ring (one stage = 32 weight rows x C = NK KB)
+// NW = 8: one block per CU, its two wave groups ping-pong (below).  NW = 4: one wave per SIMD and TWO blocks per CU (3-stage
+// ring, 64 KB of LDS each): the blocks are not coupled by barriers, so one block's prologue (its rows' activations come
+// straight from HBM: ~20 % of a block's life) and epilogues overlap the other block's MFMAs.
+template <int NK, int NW>
+__global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
+  constexpr int NS = NW == 8 ? 4 : 3;   // weight-stage ring (one stage = 32 weight rows x C = NK KB)
+  constexpr bool PP = NW == 8;
   constexpr int STAGE = NK * 1024;
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE + 3 * NK * 16 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -67,23 +71,23 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   const int ppw = 32 >> p.logf;         // pixels per wave
   // LayerNorm-fold vectors in LDS (an ordinary global load next to in-flight LDS-DMA makes hipcc drain vmcnt(0))
   float* lnc = reinterpret_cast<float*>(smem + NS * STAGE);                 // [3C] beta @ W^T (+ bias)
-  for (int i = tid; i < 3 * NK * 16; i += 512) lnc[i] = p.ln_c[i];
+  for (int i = tid; i < 3 * NK * 16; i += NW * 64) lnc[i] = p.ln_c[i];
 
   // ---- this lane's row: tile row r = (pixel r / F, frame r % F) ---------------------------------------------------------
-  const int px = (int)blockIdx.x * (8 * ppw) + wave * ppw + (r >> p.logf);
+  const int px = (int)blockIdx.x * (NW * ppw) + wave * ppw + (r >> p.logf);
   const int fr = r & (F - 1);
   const bool live = px < p.hw;
   const long grow = ((long)blockIdx.y * F + fr) * p.hw + (live ? px : 0);
 
   // ---- weight stages: piece j (1 KB) of a stage is issued by wave j % 8 ---------------------------------------------------
-  const int pw = (NK - wave + 7) / 8;   // pieces of this wave per stage (wave-uniform)
+  const int pw = (NK - wave + NW - 1) / NW;   // pieces of this wave per stage (wave-uniform)
   const int T = p.heads * 6;
   auto issue = [&](int st) {
     const char* src = reinterpret_cast<const char*>(p.wp) + (size_t)st * STAGE + lane * 16;
-    char* dst = smem + (st & (NS - 1)) * STAGE;
+    char* dst = smem + (st % NS) * STAGE;
 #pragma unroll
-    for (int i = 0; i < (NK + 7) / 8; ++i) {
-      const int j = wave + 8 * i;
+    for (int i = 0; i < (NK + NW - 1) / NW; ++i) {
+      const int j = wave + NW * i;
       if (j < NK)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
                                          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   auto wait_stage = [&](int st, int issued_beyond) {  // this wave's pieces of stage st have landed (later stages may stay in flight)
     const int ahead = T - 1 - st < issued_beyond ? T - 1 - st : issued_beyond;  // stages issued beyond st at this point
     const int n = ahead * pw;
-    if (n >= 6) tf_wait<6>(); else if (n == 4) tf_wait<4>(); else if (n == 3) tf_wait<3>(); else if (n == 2) tf_wait<2>();
-    else if (n == 1) tf_wait<1>(); else tf_wait<0>();
+    if (n >= 10) tf_wait<10>(); else if (n == 6) tf_wait<6>(); else if (n == 5) tf_wait<5>(); else if (n == 4) tf_wait<4>();
+    else if (n == 3) tf_wait<3>(); else if (n == 2) tf_wait<2>(); else if (n == 1) tf_wait<1>(); else tf_wait<0>();
   };
 
   // ---- raw activations of the row -> registers (operand fragments), row statistics ----------------------------------------
@@ -137,11 +141,11 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   // wave, counted vmcnt) before the barrier that precedes any wave's MFMAs on it; a ring slot is refilled two barriers after
   // its last reader finished.
   int stage = 0;
-  const int grp = wave >> 2;
+  const int grp = PP ? wave >> 2 : 0;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
   unsigned long long s_bm = 0, s_is = 0, s_mf = 0, s_wt = 0, s_be = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)t5; (void)s_bm; (void)s_is; (void)s_mf; (void)s_wt; (void)s_be;
-  wait_stage(0, 2);
+  wait_stage(0, NS - 2);
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 #ifdef MVOC_PP_LAB
@@ -154,14 +158,37 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
   constexpr int PD = NK < 8 ? NK : 8;
   half8_t wf[PD];
   auto prefetch = [&](int st) {
-    const char* wl = smem + (st & (NS - 1)) * STAGE + lane * 16;
+    const char* wl = smem + (st % NS) * STAGE + lane * 16;
 #pragma unroll
     for (int i = 0; i < PD; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 1024);
   };
-  prefetch(0);
+  if constexpr (PP) prefetch(0);
   // one weight stage: acc += (32 weight rows) x (this wave's 32 activation rows); w_rows: weights are the row operand.
   //     bar_M ; MFMAs(stage) ; wait(stage+1 landed) ; bar_E ; first reads of stage+1 ; issue stage+3   | caller: epilogue(stage)
   auto run_stage = [&](f32x16& acc, bool w_rows) {
+    if constexpr (!PP) {
+      // one wave per SIMD, one barrier per stage: stage landed for every wave (and stage-1's readers are done) -> refill the
+      // slot of stage-1 with stage+2, multiply, then the caller's epilogue; the CU's other block fills the gaps
+      wait_stage(stage, NS - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (stage + NS - 1 < T) issue(stage + NS - 1);
+      const char* wl = smem + (stage % NS) * STAGE + lane * 16;
+#pragma unroll
+      for (int i = 0; i < PD; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 1024);
+      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+        acc = w_rows ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PD], xf[s], acc, 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[s], wf[s % PD], acc, 0, 0, 0);
+        if (s + PD < NK) wf[s % PD] = *reinterpret_cast<const half8_t*>(wl + (s + PD) * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      ++stage;
+      return;
+    }
     TF_STAMP(t3);
     // stage+1 must have landed for EVERY wave before the barrier after which the partner group pre-reads it (its bar_E is this
     // group's bar_M): pieces are issued through stage+2 at this point
@@ -174,7 +201,7 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
 #ifdef MVOC_PP_LAB
     s_wt += t0 - t3;
 #endif
-    const char* wl = smem + (stage & (NS - 1)) * STAGE + lane * 16;
+    const char* wl = smem + (stage % NS) * STAGE + lane * 16;
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
       acc = w_rows ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PD], xf[s], acc, 0, 0, 0)
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(512) void tfused_kernel(const TfArgs p) {
       }
     }
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // group A's balancing barrier
+  if (PP && grp == 0) __builtin_amdgcn_s_barrier();  // group A's balancing barrier
 #ifdef MVOC_PP_LAB
   TF_STAMP(t0);
   if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4) && lane == 0) {
@@ -326,13 +353,21 @@ extern "C" int mvoc_temporal_qkv_attn_f16(const mvoc_tfused_desc* d, void* strea
 #ifdef MVOC_PP_LAB
   if (const char* e = getenv("MVOC_TF_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 10);
 #endif
-  const int ppb = 8 * (32 / d->frames);  // pixels per block
+  static const int mode = getenv("MVOC_TFUSED_WAVES") ? atoi(getenv("MVOC_TFUSED_WAVES")) : 4;  // 8: one ping-pong block per CU
+  const int nw = mode == 8 ? 8 : 4;
+  const int ppb = nw * (32 / d->frames);  // pixels per block
   dim3 grid((unsigned)((d->hw + ppb - 1) / ppb), (unsigned)d->nsample);
   hipStream_t s = (hipStream_t)stream;
   const double rows = (double)d->nsample * d->frames * d->hw;
   MvocProfScope prof(MVOC_FAM_TATTN, s, 2.0 * rows * 3.0 * d->c * d->c + 4.0 * rows * d->frames * d->c);
-  if (d->c == 320) hipLaunchKernelGGL(tfused_kernel<20>, grid, dim3(512), 0, s, a);
-  else if (d->c == 128) hipLaunchKernelGGL(tfused_kernel<8>, grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL(tfused_kernel<4>, grid, dim3(512), 0, s, a);
+  if (nw == 8) {
+    if (d->c == 320) hipLaunchKernelGGL((tfused_kernel<20, 8>), grid, dim3(512), 0, s, a);
+    else if (d->c == 128) hipLaunchKernelGGL((tfused_kernel<8, 8>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((tfused_kernel<4, 8>), grid, dim3(512), 0, s, a);
+  } else {
+    if (d->c == 320) hipLaunchKernelGGL((tfused_kernel<20, 4>), grid, dim3(256), 0, s, a);
+    else if (d->c == 128) hipLaunchKernelGGL((tfused_kernel<8, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((tfused_kernel<4, 4>), grid, dim3(256), 0, s, a);
+  }
   return mvoc_check_launch("tfused_kernel");
 }
