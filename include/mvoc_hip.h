@@ -110,6 +110,26 @@ typedef struct mvoc_tattn_desc {
 } mvoc_tattn_desc;
 int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream);
 
+/* Activation-stationary linear for K in {64, 128, 320} (the 320-channel level's projections: F.linear at pnp_utils.py:191, 206,
+ * 335, 438, 505, 604-612, 692): out[m][n] = epi(x[m][:] . W[n][:]).  A wave keeps 32 consecutive rows of x in registers; the
+ * weights stream through LDS from a fragment-ordered copy
+ *   wp [n/32 tiles][k/16 steps][lane < 64][8 fp16], element = W[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j]   (mvoc_amd.unet.pack_xs_weights)
+ * normalize != 0 folds a LayerNorm in front (rows normalised in registers; W must be gamma-scaled, cvec = beta @ W^T + bias, fp32 [n]);
+ * otherwise bias (fp16 [n]) or cvec may be given.  act as for mvoc_gemm_f16 (GEGLU: weight rows in (value, gate) blocks of 32,
+ * n/2 outputs, no residual).  x is [m][k] contiguous; out / resid rows 16-byte addressable per 8 channels. */
+typedef struct mvoc_xs_desc {
+  const void* x;
+  const void* wp;
+  const void* bias;
+  const void* cvec;
+  const void* resid;
+  void* out;
+  int64_t m;
+  int32_t n, k, n_store, ldo, ldr, act, normalize;
+  float ln_eps;
+} mvoc_xs_desc;
+int mvoc_xs_linear_f16(const mvoc_xs_desc* d, void* stream);
+
 /* Fused front half of a temporal self-attention at the finest level: LayerNorm -> to_q/to_k/to_v -> attention over the frame
  * axis, Q/K/V never written to HBM (TransformerTemporalModel's attn1 / attn2: pnp_utils.py:170-220, 222-346, 720-887; replaces
  * mvoc_row_stats_f16 + the fused-QKV mvoc_gemm_f16 + mvoc_temporal_attn_f16 where no PnP Q/K injection is scheduled).

@@ -56,6 +56,11 @@ class TFusedDesc(C.Structure):
                 ("hw", i32), ("c", i32), ("heads", i32), ("ln_eps", f32)]
 
 
+class XsDesc(C.Structure):
+    _fields_ = [("x", vp), ("wp", vp), ("bias", vp), ("cvec", vp), ("resid", vp), ("out", vp), ("m", i64), ("n", i32), ("k", i32),
+                ("n_store", i32), ("ldo", i32), ("ldr", i32), ("act", i32), ("normalize", i32), ("ln_eps", f32)]
+
+
 class PnpDesc(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("masks", vp), ("chunk_stride", i64), ("f_stride", i64), ("p_stride", i64),
                 ("nobj", i32), ("frames", i32), ("height", i32), ("width", i32), ("channels", i32), ("mask_h", i32),
@@ -71,6 +76,7 @@ SIGNATURES = {
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),
+    "mvoc_xs_linear_f16": (i32, [C.POINTER(XsDesc), vp]),
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
     "mvoc_groupnorm_moments_f16": (i32, [C.POINTER(GnDesc), vp, vp]),

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
   // LayerNorm-fold vectors in LDS (an ordinary global load next to in-flight LDS-DMA makes hipcc drain vmcnt(0))
   float* lnc = reinterpret_cast<float*>(smem + NS * STAGE);                 // [3C] beta @ W^T (+ bias)
   for (int i = tid; i < 3 * NK * 16; i += NW * 64) lnc[i] = p.ln_c[i];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before the first (raw) barrier below releases any reader
 
   // ---- this lane's row: tile row r = (pixel r / F, frame r % F) ---------------------------------------------------------
   const int px = (int)blockIdx.x * (NW * ppw) + wave * ppw + (r >> p.logf);

@@ -9,7 +9,7 @@ import torch
 
 from . import _ffi
 from ._ffi import (A_CONV3X3, A_PLAIN, A_TEMPORAL3, ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, AttnDesc, GemmDesc, GnDesc,
-                   PnpDesc, TAttnDesc, TFusedDesc, check, lib)
+                   PnpDesc, TAttnDesc, TFusedDesc, XsDesc, check, lib)
 
 __all__ = ["linear", "conv3x3", "tconv3", "flash_attn", "temporal_attn", "groupnorm", "groupnorm_moments", "groupnorm_apply_moments", "layernorm", "pnp_blend_tokens",
            "pnp_blend_nchw", "ddim_step", "latent_fusion", "timestep_embedding", "act", "add", "conv3x3_small",
@@ -181,6 +181,29 @@ def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
         setattr(d, name + "_bs", frames * hw * ld)
     d.nsample, d.hw, d.heads, d.frames = nsample, hw, heads, frames
     check(lib.mvoc_temporal_attn_f16(C.byref(d), _stream()), "temporal_attn")
+    return out
+
+
+XS_K = (64, 128, 320)   # activation-stationary kernels: the rows' K channels live in registers
+XS_NMAX = 2560
+
+
+def xs_linear(x, wp, n, *, bias=None, cvec=None, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, n_store=0, out=None):
+    """activation-stationary linear (include/mvoc_hip.h: mvoc_xs_linear_f16): x contiguous [m, k], wp fragment-packed [n, k]
+    weights; ``normalize``: LayerNorm folded (rows normalised in registers; wp gamma-scaled, cvec = beta @ W^T + bias)"""
+    _chk(x, "x"), _chk(wp, "wp"), _chk(bias, "bias"), _chk(cvec, "cvec", torch.float32), _chk(resid, "resid")
+    m, k = x.shape
+    if not x.is_contiguous() or wp.numel() != n * k:
+        raise RuntimeError("xs_linear: x must be contiguous [m, k] and wp hold n*k packed weights")
+    cols = n // 2 if act == ACT_GEGLU else (n_store if n_store else n)
+    if out is None:
+        out = torch.empty((m, cols), dtype=torch.float16, device=x.device)
+    d = XsDesc()
+    d.x, d.wp, d.bias, d.cvec, d.resid, d.out = x.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(cvec), _ptr(resid), out.data_ptr()
+    d.m, d.n, d.k, d.n_store, d.ldo = m, n, k, cols, _rowmajor(out, "out")
+    d.ldr = _rowmajor(resid, "resid") if resid is not None else 0
+    d.act, d.normalize, d.ln_eps = act, int(bool(normalize)), eps
+    check(lib.mvoc_xs_linear_f16(C.byref(d), _stream()), "xs_linear")
     return out
 
 

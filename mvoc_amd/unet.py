@@ -75,6 +75,13 @@ def pack_geglu(w, b):
     return w[src].contiguous(), b[src].contiguous()
 
 
+def pack_xs_weights(w):
+    """[N, K] (N % 32 == 0, K % 16 == 0) -> MFMA fragment order for mvoc_xs_linear_f16: [tile][k16 step][lane][8],
+    element = W[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
+    n, k = w.shape
+    return w.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def pack_tfused_weights(wqkv, heads):
     """[3C, C] gamma-scaled QKV weights -> MFMA fragment order for mvoc_temporal_qkv_attn_f16:
     [head][tile q0 k0 q1 k1 v0 v1][k16 step][lane][8], element = W[row0 + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
@@ -123,8 +130,28 @@ class Linear:
             self.b = torch.zeros(self.w.shape[0], dtype=H16, device=w.device)
             self.b[:self.n] = b.to(H16)
         self.ln = None
+        self.wp = None      # fragment-packed copies for the activation-stationary kernel (made on first use)
+        self.wp_ln = None
+
+    XS_MIN_ROWS = 4096  # below this the launch is latency-bound either way; the tiled GEMM has split-K for deep K
+
+    def _xs_ok(self, x, kw):
+        """the activation-stationary kernel takes this call: K in registers (64 / 128 / 320), single contiguous source, plain
+        epilogue (bias | folded LayerNorm constant, activation, residual), many rows"""
+        k = self.w.shape[1]
+        return (Linear.use_xs and k in ops.XS_K and self.w.shape[0] <= ops.XS_NMAX and x.shape[0] >= self.XS_MIN_ROWS and
+                x.dim() == 2 and x.shape[1] == k and x.is_contiguous() and
+                not (set(kw) - {"act", "resid", "out"}) and (kw.get("resid") is None or kw.get("act", ACT_NONE) != ACT_GEGLU) and
+                (self.n % 8 == 0 if kw.get("act", ACT_NONE) != ACT_GEGLU else True) and
+                (kw.get("out") is None or kw["out"].stride(0) % 8 == 0) and (kw.get("resid") is None or kw["resid"].stride(0) % 8 == 0))
+
+    use_xs = True
 
     def __call__(self, x, **kw):
+        if self._xs_ok(x, kw):
+            if self.wp is None:
+                self.wp = pack_xs_weights(self.w)
+            return ops.xs_linear(x, self.wp, self.w.shape[0], bias=self.b, n_store=self.n, **kw)
         return ops.linear(x, self.w, self.b, n_store=self.n, **kw)
 
     def fold_layernorm(self, gamma, beta, eps=1e-5):
@@ -146,6 +173,13 @@ class Linear:
         """x: raw rows; norm = (gamma, beta) of the LayerNorm that precedes this linear"""
         if self.ln is None:
             return self(ops.layernorm(x, *norm), **kw)
+        if self._xs_ok(x, kw):
+            # rows normalised in registers, gamma on the weights, beta @ W^T + bias as the per-channel constant: no statistics
+            # pass, no LayerNorm tensor, no row-sum correction
+            if self.wp_ln is None:
+                self.wp_ln = pack_xs_weights(self.w_ln)
+            return ops.xs_linear(x, self.wp_ln, self.w_ln.shape[0], cvec=self.ln[1], normalize=True, eps=self.ln[2],
+                                 n_store=self.n, **kw)
         stats = ops.row_stats(x, self.ln[2])  # one read of the rows; every n-tile of the GEMM shares it
         return ops.linear(x, self.w_ln, None, n_store=self.n, ln=self.ln + (stats,), **kw)
 

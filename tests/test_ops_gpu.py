@@ -465,6 +465,105 @@ def test_temporal_qkv_attn_fused(ops, c, frames, hw, ns):
     assert rel_l2(out, un) < 2e-3
 
 
+# ---- activation-stationary linear (csrc/xslin.hip) ------------------------------------------------------------------------
+@pytest.mark.parametrize("k,n,m", [(320, 320, 4096), (320, 960, 1000), (64, 64, 129), (128, 384, 4097), (320, 2560, 300)])
+def test_xs_linear_exact(ops, k, n, m):
+    """small-integer operands: every product and partial sum is exact in fp32 and the result exact in fp16 -> bit-equal to the
+    integer answer whatever the accumulation order (bias and residual included; ragged row counts)"""
+    from mvoc_amd.unet import pack_xs_weights
+    g = torch.Generator().manual_seed(k + n + m)
+    x = torch.randint(-3, 4, (m, k), generator=g).half()
+    w = torch.randint(-2, 3, (n, k), generator=g).half()
+    b = torch.randint(-8, 9, (n,), generator=g).half()
+    r = torch.randint(-16, 17, (m, n), generator=g).half()
+    ref = x.double() @ w.double().t() + b.double()
+    assert ref.abs().max() < 2048
+    out = ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b))
+    assert torch.equal(out.cpu().double(), ref)
+    out = ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b), resid=dev(r))
+    assert torch.equal(out.cpu().double(), ref + r.double())
+    # a narrower store (padded weight rows) into a wider row pitch
+    wide = torch.full((m, n + 64), 7.0, dtype=torch.float16, device="cuda")
+    ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b), n_store=n - 24, out=wide[:, 8:8 + n - 24])
+    assert torch.equal(wide[:, 8:8 + n - 24].cpu().double(), ref[:, :n - 24])
+    assert (wide[:, :8] == 7).all() and (wide[:, 8 + n - 24:] == 7).all()
+
+
+@pytest.mark.parametrize("k,n,m,act", [(320, 320, 5000, "none"), (320, 960, 4096, "silu"), (128, 256, 4500, "gelu"), (320, 2560, 4100, "geglu"),
+                                       (64, 128, 4096, "geglu")])
+def test_xs_linear_matches_tiled_gemm(ops, k, n, m, act):
+    """the activation-stationary kernel against torch and against the tiled GEMM of this library on the same operands: same
+    fp16 rounding points (bias add, activation, residual), so the two differ by accumulation order only"""
+    from mvoc_amd._ffi import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU
+    from mvoc_amd.unet import Linear, pack_geglu
+    a = {"none": ACT_NONE, "silu": ACT_SILU, "gelu": ACT_GELU, "geglu": ACT_GEGLU}[act]
+    g = torch.Generator().manual_seed(k + n + m)
+    x = torch.randn(m, k, generator=g).half()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).half()
+    b = (0.2 * torch.randn(n, generator=g)).half()
+    y = x.float() @ w.float().t() + b.float()
+    if act == "geglu":
+        ref = y[:, :n // 2].half().float() * F.gelu(y[:, n // 2:].half().float()).half().float()
+        wd, bd = pack_geglu(dev(w), dev(b))
+    else:
+        ref = {"none": lambda t: t, "silu": F.silu, "gelu": F.gelu}[act](y.half().float())
+        wd, bd = dev(w), dev(b)
+    lin = Linear(wd, bd)
+    kw = {} if act == "geglu" else {"resid": dev(x[:, :1].expand(m, n).contiguous())}
+    if kw:
+        ref = ref.half().float() + x[:, :1].float()
+    assert lin._xs_ok(dev(x), dict(act=a, **kw))
+    out = lin(dev(x), act=a, **kw)
+    assert lin.wp is not None
+    assert rel_l2(out, ref) < 1.5e-3, rel_l2(out, ref)
+    Linear.use_xs = False
+    try:
+        old = lin(dev(x), act=a, **kw)
+    finally:
+        Linear.use_xs = True
+    assert rel_l2(out, old) < 6e-4, rel_l2(out, old)
+    assert (out.float() - old.float()).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("k,n,m", [(320, 960, 4096), (320, 2560, 4200), (128, 384, 5000), (64, 192, 4096)])
+def test_xs_linear_layernorm_fold(ops, k, n, m):
+    """LayerNorm folded by normalising the register-resident rows: against F.layer_norm -> F.linear with the reference's fp16
+    LayerNorm output, and against this library's row-statistics + folded-GEMM path"""
+    from mvoc_amd._ffi import ACT_GEGLU, ACT_NONE
+    from mvoc_amd.unet import Linear, pack_geglu
+    geglu = n == 2560
+    g = torch.Generator().manual_seed(k + n)
+    x = (torch.randn(m, k, generator=g) * 1.7 + 0.4).half()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).half()
+    b = (0.2 * torch.randn(n, generator=g)).half()
+    gm, bt = (1 + 0.3 * torch.randn(k, generator=g)).half(), (0.3 * torch.randn(k, generator=g)).half()
+    y = F.layer_norm(x.float(), (k,), gm.float(), bt.float(), 1e-5).half().float() @ w.float().t() + b.float()
+    if geglu:
+        ref = y[:, :n // 2].half().float() * F.gelu(y[:, n // 2:].half().float()).half().float()
+        wd, bd = pack_geglu(dev(w), dev(b))
+    else:
+        ref, wd, bd = y, dev(w), dev(b)
+    lin = Linear(wd, bd).fold_layernorm(dev(gm), dev(bt))
+    kw = {"act": ACT_GEGLU if geglu else ACT_NONE}
+    out = lin.call_ln(dev(x), (dev(gm), dev(bt)), **kw)
+    assert lin.wp_ln is not None
+    assert rel_l2(out, ref) < 2.5e-3, rel_l2(out, ref)
+    Linear.use_xs = False
+    try:
+        old = lin.call_ln(dev(x), (dev(gm), dev(bt)), **kw)
+    finally:
+        Linear.use_xs = True
+    assert rel_l2(out, old) < 2.5e-3, rel_l2(out, old)
+
+
+def test_xs_linear_refuses(ops):
+    from mvoc_amd.unet import pack_xs_weights
+    x = torch.zeros(64, 96, dtype=torch.float16, device="cuda")
+    w = torch.zeros(32, 96, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="xs_linear"):
+        ops.xs_linear(x, pack_xs_weights(w), 32)
+
+
 # ---- norms ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,groups,rows,nsample,silu", [(320, 32, 64, 5, True), (64, 8, 37, 3, False), (2560, 32, 16, 2, True),
                                                         (960, 32, 100, 4, True), (128, 8, 4096, 2, False)])
