@@ -88,7 +88,7 @@ size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k);
 /* ---------------------------------------------------------------------------------------------
  * Attention, head_dim 64, softmax(Q K^T / 8) V, no mask (F.scaled_dot_product_attention at
  * pnp_utils.py:684-686, 862-864 and the stock AttnProcessor2_0 sites).
- * q/k/v/out element (b, t, h, d) lives at base + b*bs + t*ts + h*64 + d  (elements).
+ * q/k/v/out element (b, t, h, d) lives at base + b*bs + t*ts + h*head_dim + d  (elements).
  * kv batch index = b / kv_bdiv (cross-attention context shared by all frames of a sample).
  * ------------------------------------------------------------------------------------------- */
 typedef struct mvoc_attn_desc {
@@ -96,6 +96,11 @@ typedef struct mvoc_attn_desc {
   void* out;
   int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
   int32_t nbatch, heads, tq, tk, kv_bdiv;
+  /* the three below default (0) to the UNet's form: head_dim 64, no mask, scale 1/8.  head_dim 96 with scale 1/sqrt(80)
+   * serves CLIP ViT-H's 80-wide heads (projection weights zero-padded per head); causal: key <= query (CLIP text tower,
+   * pipeline_i2vgen_xl.py:552-737 encode_prompt -> CLIPTextModel) */
+  int32_t head_dim, causal;
+  float scale;
 } mvoc_attn_desc;
 
 /* spatial self-attention and image/text cross-attention (flash-style, K/V tiles LDS-staged) */
@@ -290,6 +295,19 @@ int mvoc_mask_resize_u8(const void* in, void* tmp, void* out, int32_t n, int32_t
                         const int32_t* bounds_h, const int32_t* kk_h, int32_t ksize_h, const int32_t* bounds_v,
                         const int32_t* kk_v, int32_t ksize_v, void* stream);
 int mvoc_mask_finish(const void* v, void* float_mask, void* bool_mask, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conditioning prep: the embedding stages of the CLIP towers the reference runs through transformers
+ * (pipeline_i2vgen_xl.py:739-769 `_encode_image` -> CLIPVisionModelWithProjection, :552-737 `encode_prompt` -> CLIPTextModel);
+ * the transformer stacks themselves are mvoc_gemm_f16 / mvoc_layernorm_f16 / mvoc_flash_attn_f16 (head_dim 96 | causal).
+ *   clip_patches: NCHW fp16 pixels [nimg,3,size,size] -> im2col rows [nimg*(size/patch)^2, kpad] of the patch-embedding conv
+ *                 (k = (c, py, px) like Conv2d's weight.view(N, -1); columns >= 3*patch^2 are zero)
+ *   clip_embed  : out[row] = src(row) + pos[row % t]; src = table[ids[row]] (text: token + position embedding), or with
+ *                 ids == NULL the class embedding at t == 0 and patch row (row/t)*(t-1) + (row%t) - 1 otherwise (vision)
+ * ------------------------------------------------------------------------------------------- */
+int mvoc_clip_patches_f16(const void* pixels, void* out, int32_t nimg, int32_t size, int32_t patch, int32_t kpad, void* stream);
+int mvoc_clip_embed_f16(const void* table, const int32_t* ids, const void* cls, const void* pos, void* out, int64_t rows,
+                        int32_t t, int32_t c, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * RCCL exchanges of the frame-axis shard (SURVEY 8b `allgather_frames`, 8e / BASELINE configs[3]: one long clip over the GPUs

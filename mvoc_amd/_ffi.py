@@ -35,7 +35,8 @@ class AttnDesc(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp),
                 ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ts", i64), ("v_bs", i64), ("v_ts", i64),
                 ("o_bs", i64), ("o_ts", i64),
-                ("nbatch", i32), ("heads", i32), ("tq", i32), ("tk", i32), ("kv_bdiv", i32)]
+                ("nbatch", i32), ("heads", i32), ("tq", i32), ("tk", i32), ("kv_bdiv", i32),
+                ("head_dim", i32), ("causal", i32), ("scale", C.c_float)]
 
 
 class TAttnDesc(C.Structure):
@@ -104,6 +105,8 @@ SIGNATURES = {
     "mvoc_mask_resize_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
     "mvoc_mask_finish": (i32, [vp, vp, vp, i64, vp]),
     "mvoc_permute_rows_f16": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), i32, vp]),
+    "mvoc_clip_patches_f16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "mvoc_clip_embed_f16": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "mvoc_comm_unique_id": (i32, [vp]),
     "mvoc_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
     "mvoc_comm_destroy": (i32, [vp]),

@@ -21,14 +21,15 @@
 namespace {
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-constexpr int KPITCH = 144;
-constexpr int VPITCH = 192;  // flash kernel: row-major V rows of 128 B + 64 B pad (4 consecutive rows hit 4 disjoint 64-byte bank windows)
+// flash kernel LDS pitches for head dim D: K rows of 2D bytes + 16 (an odd number of 16-byte units: conflict-free b128 reads);
+// V rows row-major with a pitch == 64 or 192 (mod 256): the 4 rows of a transposed read hit 4 disjoint 64-byte bank windows
+template <int D> struct FlashPitch { static constexpr int K = 2 * D + 16, V = D == 64 ? 192 : 320; };
 
 struct AttnArgs {
   const half_t *q, *k, *v;
   half_t* out;
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
-  int nbatch, heads, tq, tk, kv_bdiv;
+  int nbatch, heads, tq, tk, kv_bdiv, causal;
   float scale_log2;
 };
 
@@ -37,7 +38,10 @@ __device__ __forceinline__ int vt_slot_group(int key) {  // 16-byte group (8 slo
 }
 __device__ __forceinline__ int vt_slot_elem(int key) { return ((key >> 3) & 1) * 4 + (key & 3); }
 
+template <int D>  // head dim: 64 (the UNet), 96 (CLIP ViT-H's 80, zero-padded by the projection weights)
 __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
+  constexpr int KPITCH = FlashPitch<D>::K, VPITCH = FlashPitch<D>::V;
+  constexpr int ND = D / 16, NT = D / 32, CPK = D / 8, NCH = 64 * CPK / 256;  // k steps, output tiles, 16-byte chunks per key / thread
   __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + 64 * VPITCH];
   char* Ks = smem;
   char* Vs = smem + 64 * KPITCH;
@@ -46,30 +50,30 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   const int head = blockIdx.y, b = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wave * 32;
 
-  const half_t* qp = p.q + (long)b * p.q_bs + head * 64;
+  const half_t* qp = p.q + (long)b * p.q_bs + head * D;
   const int qrow = min(q0 + r, p.tq - 1);
-  half8_t qf[4];
+  half8_t qf[ND];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
+  for (int s = 0; s < ND; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
 
-  const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * 64;
-  const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * 64;
+  const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * D;
+  const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * D;
 
-  f32x16 ot[2];
+  f32x16 ot[NT];
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < NT; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
 
   const int ntiles = (p.tk + 63) / 64;
-  half8_t kreg[2], vreg[2];
+  half8_t kreg[NCH], vreg[NCH];
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * 256;
-      const int key = kt * 64 + (c >> 3), dc = c & 7;
+      const int key = kt * 64 + c / CPK, dc = c % CPK;
       kreg[i] = zero8;
       vreg[i] = zero8;
       if (key < p.tk) {
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = tid + i * 256;
-      const int key = c >> 3, dc = c & 7;
+      const int key = c / CPK, dc = c % CPK;
       *reinterpret_cast<half8_t*>(Ks + key * KPITCH + dc * 16) = kreg[i];
       *reinterpret_cast<half8_t*>(Vs + key * VPITCH + dc * 16) = vreg[i];  // row-major; transposed on the read (below)
     }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < ND; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (32 * t + r) * KPITCH + (16 * s + 8 * h) * 2);
         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[t], 0, 0, 0);
       }
@@ -110,6 +114,13 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (kt * 64 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3) >= p.tk) st[t][e] = -INFINITY;
+    }
+    if (p.causal) {  // CLIP text tower: a query sees keys <= itself (key 0 is always visible, so the running maximum stays finite)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (kt * 64 + 32 * t + 8 * (e >> 2) + 4 * h + (e & 3) > q0 + r) st[t][e] = -INFINITY;
     }
     float mx = st[0][0];
 #pragma unroll
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
       mrun = mnew;
       lrun *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < NT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
     }
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
         // accumulator's k order is two runs of 4 consecutive keys (32t + 16s + 4h + {0..3} and + 8): two reads.
         const int krow = 32 * t + 16 * s + 4 * h + ((lane & 15) >> 2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+        for (int dt = 0; dt < NT; ++dt) {
           const char* va = Vs + krow * VPITCH + (32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
           const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
           const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 8 * VPITCH));
@@ -169,9 +180,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   const float ltot = lrun + __shfl_xor(lrun, 32);
   const float inv = 1.0f / ltot;
   if (q0 + r < p.tq) {
-    half_t* op = p.out + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * 64;
+    half_t* op = p.out + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * D;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < NT; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         half4_t o;
@@ -304,11 +315,16 @@ extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   a.q_bs = d->q_bs; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_ts = d->k_ts; a.v_bs = d->v_bs; a.v_ts = d->v_ts;
   a.o_bs = d->o_bs; a.o_ts = d->o_ts;
   a.nbatch = d->nbatch; a.heads = d->heads; a.tq = d->tq; a.tk = d->tk; a.kv_bdiv = d->kv_bdiv > 0 ? d->kv_bdiv : 1;
-  a.scale_log2 = 0.125f * 1.4426950408889634f;
+  const int hd = d->head_dim > 0 ? d->head_dim : 64;
+  MVOC_REQUIRE(hd == 64 || hd == 96, -2, "flash_attn: head_dim (%d) must be 64 or 96", hd);
+  MVOC_REQUIRE(!d->causal || d->tq == d->tk, -2, "flash_attn: the causal form is self-attention (tq == tk)");
+  a.causal = d->causal;
+  a.scale_log2 = (d->scale > 0.f ? d->scale : (hd == 64 ? 0.125f : 1.0f / sqrtf((float)hd))) * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  MvocProfScope prof(MVOC_FAM_FLASH, s, 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * 64);
+  MvocProfScope prof(MVOC_FAM_FLASH, s, 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * hd);
   dim3 grid((d->tq + 127) / 128, d->heads, d->nbatch);
-  hipLaunchKernelGGL(flash_kernel, grid, dim3(256), 0, s, a);
+  if (hd == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(flash_kernel<96>, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("flash_kernel");
 }
 

@@ -210,6 +210,47 @@ __global__ void delay_kernel(long ticks) {
 
 inline unsigned nblk(long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
+// CLIP towers (clip.py): the two embedding stages either side of the transformer stacks
+// non-overlapping patches of NCHW pixels -> im2col rows [B * g * g, kpad], k = (c, py, px) as Conv2d's weight.view(N, -1); pad = 0
+__global__ __launch_bounds__(256) void clip_patches_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, int size, int patch,
+                                                           int kpad, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int g = size / patch;
+  const int k = (int)(i % kpad);
+  const long row = i / kpad;
+  half_t v = (half_t)0.f;
+  if (k < 3 * patch * patch) {
+    const int c = k / (patch * patch), py = (k / patch) % patch, px = k % patch;
+    const int gx = (int)(row % g), gy = (int)((row / g) % g);
+    const long b = row / ((long)g * g);
+    v = x[((b * 3 + c) * size + gy * patch + py) * (long)size + gx * patch + px];
+  }
+  out[i] = v;
+}
+
+// out[row] = src(row) + pos[row % T]; src = table[ids[row]] (text tower) or, ids == NULL, the class embedding at t == 0 and
+// patch row (row / T) * (T - 1) + t - 1 otherwise (vision tower)
+__global__ __launch_bounds__(256) void clip_embed_kernel(const half_t* __restrict__ table, const int* __restrict__ ids,
+                                                         const half_t* __restrict__ cls, const half_t* __restrict__ pos,
+                                                         half_t* __restrict__ out, int T, int c8n, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % c8n);
+  const long row = i / c8n;
+  const int t = (int)(row % T);
+  const half_t* src;
+  if (ids) src = table + ((long)ids[row] * c8n + c8) * 8;
+  else if (t == 0) src = cls + c8 * 8;
+  else src = table + (((row / T) * (T - 1) + t - 1) * c8n + c8) * 8;
+  const half8_t a = *reinterpret_cast<const half8_t*>(src);
+  const half8_t b = *reinterpret_cast<const half8_t*>(pos + ((long)t * c8n + c8) * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+  reinterpret_cast<half8_t*>(out)[i] = o;
+}
+
 }  // namespace
 
 extern "C" int mvoc_timestep_embedding_f16(const float* t_dev, int32_t nb, int32_t dim, void* out, void* stream) {
@@ -306,6 +347,29 @@ extern "C" int mvoc_gaussian_sample_f16(const void* mean, const void* logvar, co
   hipLaunchKernelGGL(gaussian_sample_kernel, dim3(nblk(n)), dim3(256), 0, s, (const half_t*)mean, (const half_t*)logvar,
                      (const half_t*)noise, (half_t*)out, (long)n);
   return mvoc_check_launch("gaussian_sample_kernel");
+}
+
+extern "C" int mvoc_clip_patches_f16(const void* pixels, void* out, int32_t nimg, int32_t size, int32_t patch, int32_t kpad,
+                                     void* stream) {
+  MVOC_REQUIRE(pixels && out && nimg > 0 && patch > 0 && size > 0 && size % patch == 0 && kpad >= 3 * patch * patch, -1,
+               "clip_patches: bad args");
+  const long total = (long)nimg * (size / patch) * (size / patch) * kpad;
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 4.0 * total);
+  hipLaunchKernelGGL(clip_patches_kernel, dim3(nblk(total)), dim3(256), 0, s, (const half_t*)pixels, (half_t*)out, size, patch, kpad, total);
+  return mvoc_check_launch("clip_patches_kernel");
+}
+
+extern "C" int mvoc_clip_embed_f16(const void* table, const int32_t* ids, const void* cls, const void* pos, void* out, int64_t rows,
+                                   int32_t t, int32_t c, void* stream) {
+  MVOC_REQUIRE(table && pos && out && rows > 0 && t > 0 && rows % t == 0 && c > 0 && c % 8 == 0 && (ids || cls), -1,
+               "clip_embed: bad args (c %% 8, rows %% t, ids or cls)");
+  const long total = rows * (c / 8);
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_MISC, s, 6.0 * rows * c);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3(nblk(total)), dim3(256), 0, s, (const half_t*)table, (const int*)ids, (const half_t*)cls,
+                     (const half_t*)pos, (half_t*)out, t, c / 8, total);
+  return mvoc_check_launch("clip_embed_kernel");
 }
 
 extern "C" int mvoc_scale_f16(const void* x, void* out, int64_t n, double scale, void* stream) {

@@ -153,16 +153,18 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     return out
 
 
-def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None):
-    """softmax(q k^T / 8) v, head_dim 64.  q [nbatch*tq, >=heads*64] / k, v [(nbatch/kv_bdiv)*tk, ..] row-major views."""
+def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=64, causal=False, scale=0.0):
+    """softmax(q k^T * scale) v.  q [nbatch*tq, >=heads*head_dim] / k, v [(nbatch/kv_bdiv)*tk, ..] row-major views.
+    head_dim 64 (scale 1/8) is the UNet's; 96 + an explicit scale + ``causal`` serve the CLIP towers (clip.py)."""
     _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
     if out is None:
-        out = torch.empty((nbatch * tq, heads * 64), dtype=torch.float16, device=q.device)
+        out = torch.empty((nbatch * tq, heads * head_dim), dtype=torch.float16, device=q.device)
     d = AttnDesc()
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     d.q_ts, d.k_ts, d.v_ts, d.o_ts = _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(out, "out")
     d.q_bs, d.k_bs, d.v_bs, d.o_bs = tq * d.q_ts, tk * d.k_ts, tk * d.v_ts, tq * d.o_ts
     d.nbatch, d.heads, d.tq, d.tk, d.kv_bdiv = nbatch, heads, tq, tk, kv_bdiv
+    d.head_dim, d.causal, d.scale = head_dim, int(bool(causal)), scale
     check(lib.mvoc_flash_attn_f16(C.byref(d), _stream()), "flash_attn")
     return out
 

@@ -43,12 +43,14 @@ class SyntheticConditioner:
     cross_attention_dim = 1024
     vae_scale_factor = 8
 
-    def __init__(self, device, cross_attention_dim=1024, vae=None):
+    def __init__(self, device, cross_attention_dim=1024, vae=None, clip=None):
         """``vae``: a ``mvoc_amd.vae.VaeCodec`` -- video / image latents and decoding then go through the HIP VAE
-         instead of the seeded stand-ins; the CLIP halves stay synthetic (8f-3 is not built)"""
+         instead of the seeded stand-ins; ``clip``: a ``mvoc_amd.clip.ClipCodec`` -- image / prompt embeddings
+        then come from the HIP CLIP towers"""
         self.device = torch.device(device)
         self.cross_attention_dim = cross_attention_dim
         self.vae = vae
+        self.clip = clip
 
     def _gen(self, *keys):
         h = hashlib.sha256("|".join(str(k) for k in keys).encode()).digest()
@@ -63,12 +65,23 @@ class SyntheticConditioner:
         return str(image)
 
     def encode_prompt(self, prompt, negative_prompt=None):
+        c = self.clip
+        if c is not None and c.text is not None and (c.tokenizer is not None or torch.is_tensor(prompt)):
+            return c.encode_prompt(prompt, negative_prompt)
         pe = torch.randn(1, 77, self.cross_attention_dim, generator=self._gen("p", prompt)).to(self.device, H16)
         ne = torch.randn(1, 77, self.cross_attention_dim, generator=self._gen("p", negative_prompt or "")).to(self.device, H16)
         return pe, ne
 
     def encode_image(self, image):
-        return torch.randn(1, 1, self.cross_attention_dim, generator=self._gen("i", self._image_key(image))).to(self.device, H16)
+        return self.encode_images([image])
+
+    def encode_images(self, images):
+        """-> [n, 1, 1024]: every image of the list in one batched pass of the vision tower (the reference loops
+        ``_encode_image`` per frame, ``pipeline_i2vgen_xl.py:1417-1427, 1501-1541``)"""
+        if self.clip is not None and self.clip.vision is not None and all(hasattr(im, "convert") for im in images):
+            return self.clip.encode_images(images)
+        return torch.cat([torch.randn(1, 1, self.cross_attention_dim, generator=self._gen("i", self._image_key(im))).to(self.device, H16)
+                          for im in images])
 
     def image_latents(self, image, num_frames, height, width):
         if self.vae is not None and hasattr(image, "convert"):
@@ -188,7 +201,12 @@ class I2VGenXLPipeline:
         if prompt_embeds is None:
             prompt_embeds, negative_prompt_embeds = c.encode_prompt(prompt, negative_prompt)
         if image_embeddings is None:
-            image_embeddings = c.encode_image(image)
+            if getattr(c, "clip", None) is not None and hasattr(image, "convert"):
+                from .vae import center_crop_wide
+                # :1116-1120 -- the stock entry crops before the CLIP resize (the composition entries resize the uncropped frame)
+                image_embeddings = c.encode_image(center_crop_wide(image, (width, width)))
+            else:
+                image_embeddings = c.encode_image(image)
         if image_latents is None:
             image_latents = c.image_latents(image, num_frames, height, width)
         if self.do_classifier_free_guidance:
@@ -445,12 +463,15 @@ class I2VGenXLPipeline:
         bg_lat2 = c.image_latents(background_image_list[0], num_frames, height, width)
         lat_all = torch.cat([bg_lat2] + obj_lat + [main_lat] * (2 if do_cfg else 1))
 
-        def emb_list(frames):
-            return torch.cat([c.encode_image(f) for f in frames], dim=1)
-
-        main_emb = emb_list(main_image_list)
-        emb_all = torch.cat([emb_list(background_image_list)] + [emb_list(fr) for fr in objs_image_list]
-                            + ([torch.zeros_like(main_emb)] if do_cfg else []) + [main_emb])
+        # every conditioning frame of the job (background, objects, main: 4 x 16 in the demo) through the vision tower at once
+        lists = [background_image_list] + list(objs_image_list) + [main_image_list]
+        flat = c.encode_images([f for fr in lists for f in fr])  # [sum F, 1, 1024]
+        embs, o = [], 0
+        for fr in lists:
+            embs.append(flat[o:o + len(fr)].transpose(0, 1))  # [1, F, 1024]
+            o += len(fr)
+        main_emb = embs[-1]
+        emb_all = torch.cat(embs[:-1] + ([torch.zeros_like(main_emb)] if do_cfg else []) + [main_emb])
         fps = torch.full((n_obj + (3 if do_cfg else 2),), float(target_fps), dtype=torch.float32, device=self.device)
         cond = dict(encoder_hidden_states=ehs.to(self.device, H16).contiguous(), image_embeddings=emb_all.to(self.device, H16).contiguous(),
                     image_latents_first=first_all.to(self.device, H16).contiguous(), image_latents=lat_all.to(self.device, H16).contiguous(), fps=fps)

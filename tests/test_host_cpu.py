@@ -249,3 +249,17 @@ def test_pil_bicubic_tables_reproduce_pil(golden_dir):
             ref = np.asarray(im.resize(size))
             got = resize8_reference(np.asarray(im), (size[1], size[0]))
             assert np.array_equal(ref, got), (name, size)
+
+
+def test_clip_pixel_values_match_the_feature_extractor():
+    """host half of `_encode_image` (pipeline_i2vgen_xl.py:742-756) + `_resize_bilinear` (:2040-2051): PIL BILINEAR resize and
+    CLIP-statistics normalisation equal transformers' CLIPImageProcessor on the same frames"""
+    import numpy as np
+    from PIL import Image
+    from mvoc_amd.clip import clip_pixel_values
+    from oracle import clip_ref
+    rng = np.random.default_rng(5)
+    frames = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in ((90, 160), (512, 512), (224, 224))]
+    a, b = clip_pixel_values(frames), clip_ref.pixel_values(frames)
+    assert a.shape == (3, 3, 224, 224) and a.dtype == torch.float32
+    assert (a - b).abs().max() < 1e-6
