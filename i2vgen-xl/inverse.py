@@ -58,6 +58,11 @@ def build_pipeline(device, synthetic):
     # VAE encode / decode either side of the loops (frames in, frames out): the checkpoint's vae/ when present; with
     # MVOC_SYNTHETIC_VAE=1 seeded weights of the same architecture; otherwise the drivers keep latents
     attach_vae(pipe, PRETRAINED_MODEL_PATH, synthetic=os.environ.get("MVOC_SYNTHETIC_VAE") == "1")
+    # CLIP towers for the prompt / image embeddings (conditioning prep): the checkpoint's image_encoder/ + text_encoder/ (+
+    # tokenizer/) when present; MVOC_SYNTHETIC_CLIP=1: seeded weights of the same architecture (the vision tower then runs,
+    # prompts stay on the seeded stand-in because no tokenizer exists without the checkpoint)
+    from mvoc_amd.clip import attach_clip
+    attach_clip(pipe, PRETRAINED_MODEL_PATH, synthetic=os.environ.get("MVOC_SYNTHETIC_CLIP") == "1")
     return pipe
 
 

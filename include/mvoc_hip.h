@@ -116,17 +116,17 @@ typedef struct mvoc_tattn_desc {
 int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream);
 
 /* Activation-stationary linear for K in {64, 128, 320} (the 320-channel level's projections: F.linear at pnp_utils.py:191, 206,
- * 335, 438, 505, 604-612, 692): out[m][n] = epi(x[m][:] . W[n][:]).  A wave keeps 32 consecutive rows of x in registers; the
- * weights stream through LDS from a fragment-ordered copy
- *   wp [n/32 tiles][k/16 steps][lane < 64][8 fp16], element = W[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j]   (mvoc_amd.unet.pack_xs_weights)
- * normalize != 0 folds a LayerNorm in front (rows normalised in registers; W must be gamma-scaled, cvec = beta @ W^T + bias, fp32 [n]);
- * otherwise bias (fp16 [n]) or cvec may be given.  act as for mvoc_gemm_f16 (GEGLU: weight rows in (value, gate) blocks of 32,
- * n/2 outputs, no residual).  x is [m][k] contiguous; out / resid rows 16-byte addressable per 8 channels. */
+ * 335, 438, 505, 604-612, 692): out[m][n] = epi(x[m][:] . W[n][:] + c[n]).  A wave keeps 32 consecutive rows of x in registers;
+ * the weights AND the per-channel constants stream through LDS from a packed copy (mvoc_amd.unet.pack_xs_weights):
+ *   wp [n/32 tiles][k/16 + 1 pieces][lane < 64][8 fp16]
+ *      piece s < k/16: element = W[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j]  (MFMA fragment order)
+ *      piece k/16    : its first 128 bytes are the tile's 32 constants c[32 tile + i] as fp32 (bias, or beta @ W^T + bias)
+ * normalize != 0 folds a LayerNorm in front (rows normalised in registers; W must be gamma-scaled, c = beta @ W^T + bias).
+ * act as for mvoc_gemm_f16 (GEGLU: weight rows in (value, gate) blocks of 32, n/2 outputs, no residual).  x is [m][k]
+ * contiguous; out / resid rows 16-byte addressable per 8 channels; n_store may only trim the last 32-channel tile. */
 typedef struct mvoc_xs_desc {
   const void* x;
   const void* wp;
-  const void* bias;
-  const void* cvec;
   const void* resid;
   void* out;
   int64_t m;

@@ -58,8 +58,9 @@ class TFusedDesc(C.Structure):
 
 
 class XsDesc(C.Structure):
-    _fields_ = [("x", vp), ("wp", vp), ("bias", vp), ("cvec", vp), ("resid", vp), ("out", vp), ("m", i64), ("n", i32), ("k", i32),
-                ("n_store", i32), ("ldo", i32), ("ldr", i32), ("act", i32), ("normalize", i32), ("ln_eps", f32)]
+    _fields_ = [("x", vp), ("wp", vp), ("resid", vp), ("out", vp), ("m", i64),
+                ("n", i32), ("k", i32), ("n_store", i32), ("ldo", i32), ("ldr", i32), ("act", i32), ("normalize", i32),
+                ("ln_eps", C.c_float)]
 
 
 class PnpDesc(C.Structure):

@@ -187,21 +187,21 @@ def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
 
 
 XS_K = (64, 128, 320)   # activation-stationary kernels: the rows' K channels live in registers
-XS_NMAX = 2560
 
 
-def xs_linear(x, wp, n, *, bias=None, cvec=None, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, n_store=0, out=None):
-    """activation-stationary linear (include/mvoc_hip.h: mvoc_xs_linear_f16): x contiguous [m, k], wp fragment-packed [n, k]
-    weights; ``normalize``: LayerNorm folded (rows normalised in registers; wp gamma-scaled, cvec = beta @ W^T + bias)"""
-    _chk(x, "x"), _chk(wp, "wp"), _chk(bias, "bias"), _chk(cvec, "cvec", torch.float32), _chk(resid, "resid")
+def xs_linear(x, wp, n, *, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, n_store=0, out=None):
+    """activation-stationary linear (include/mvoc_hip.h: mvoc_xs_linear_f16): x contiguous [m, k]; wp = unet.pack_xs_weights(W
+    [n, k], constants [n]) (fragment-ordered weights + the per-channel constants); ``normalize``: LayerNorm folded (rows
+    normalised in registers; W gamma-scaled, constants = beta @ W^T + bias)"""
+    _chk(x, "x"), _chk(wp, "wp"), _chk(resid, "resid")
     m, k = x.shape
-    if not x.is_contiguous() or wp.numel() != n * k:
-        raise RuntimeError("xs_linear: x must be contiguous [m, k] and wp hold n*k packed weights")
+    if not x.is_contiguous() or k % 16 or n % 32 or wp.numel() != (n // 32) * (k // 16 + 1) * 512:
+        raise RuntimeError("xs_linear: x must be contiguous [m, k] and wp the pack_xs_weights() image of an [n, k] matrix")
     cols = n // 2 if act == ACT_GEGLU else (n_store if n_store else n)
     if out is None:
         out = torch.empty((m, cols), dtype=torch.float16, device=x.device)
     d = XsDesc()
-    d.x, d.wp, d.bias, d.cvec, d.resid, d.out = x.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(cvec), _ptr(resid), out.data_ptr()
+    d.x, d.wp, d.resid, d.out = x.data_ptr(), wp.data_ptr(), _ptr(resid), out.data_ptr()
     d.m, d.n, d.k, d.n_store, d.ldo = m, n, k, cols, _rowmajor(out, "out")
     d.ldr = _rowmajor(resid, "resid") if resid is not None else 0
     d.act, d.normalize, d.ln_eps = act, int(bool(normalize)), eps

@@ -465,7 +465,9 @@ class I2VGenXLPipeline:
 
         # every conditioning frame of the job (background, objects, main: 4 x 16 in the demo) through the vision tower at once
         lists = [background_image_list] + list(objs_image_list) + [main_image_list]
-        flat = c.encode_images([f for fr in lists for f in fr])  # [sum F, 1, 1024]
+        allf = [f for fr in lists for f in fr]
+        # (a conditioner without the batched entry -- the documented interface is encode_image -- is called per frame)
+        flat = c.encode_images(allf) if hasattr(c, "encode_images") else torch.cat([c.encode_image(f) for f in allf])  # [sum F, 1, 1024]
         embs, o = [], 0
         for fr in lists:
             embs.append(flat[o:o + len(fr)].transpose(0, 1))  # [1, F, 1024]

@@ -20,6 +20,7 @@ Forward entry points follow the reference:
                         ``image_latents_first`` and ``multi_frame_guidance``
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -75,11 +76,17 @@ def pack_geglu(w, b):
     return w[src].contiguous(), b[src].contiguous()
 
 
-def pack_xs_weights(w):
-    """[N, K] (N % 32 == 0, K % 16 == 0) -> MFMA fragment order for mvoc_xs_linear_f16: [tile][k16 step][lane][8],
-    element = W[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j]"""
+def pack_xs_weights(w, consts=None):
+    """[N, K] (N % 32 == 0, K % 16 == 0) + per-channel constants [N] -> the stream mvoc_xs_linear_f16 reads:
+    [tile][K/16 + 1 pieces][lane 64][8]; piece s < K/16 in MFMA fragment order (element = W[32 tile + (lane & 31)][16 s +
+    8 (lane >> 5) + j]), the last piece starts with the tile's 32 constants as fp32"""
     n, k = w.shape
-    return w.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    nk = k // 16
+    out = torch.zeros((n // 32, nk + 1, 512), dtype=H16, device=w.device)
+    out[:, :nk] = w.view(n // 32, 32, nk, 2, 8).permute(0, 2, 3, 1, 4).reshape(n // 32, nk, 512)
+    if consts is not None:
+        out[:, nk, :64] = consts.to(torch.float32).reshape(n // 32, 32).contiguous().view(H16)
+    return out
 
 
 def pack_tfused_weights(wqkv, heads):
@@ -139,19 +146,19 @@ class Linear:
         """the activation-stationary kernel takes this call: K in registers (64 / 128 / 320), single contiguous source, plain
         epilogue (bias | folded LayerNorm constant, activation, residual), many rows"""
         k = self.w.shape[1]
-        return (Linear.use_xs and k in ops.XS_K and self.w.shape[0] <= ops.XS_NMAX and x.shape[0] >= self.XS_MIN_ROWS and
+        return (Linear.use_xs and k in ops.XS_K and x.shape[0] >= self.XS_MIN_ROWS and
                 x.dim() == 2 and x.shape[1] == k and x.is_contiguous() and
                 not (set(kw) - {"act", "resid", "out"}) and (kw.get("resid") is None or kw.get("act", ACT_NONE) != ACT_GEGLU) and
                 (self.n % 8 == 0 if kw.get("act", ACT_NONE) != ACT_GEGLU else True) and
                 (kw.get("out") is None or kw["out"].stride(0) % 8 == 0) and (kw.get("resid") is None or kw["resid"].stride(0) % 8 == 0))
 
-    use_xs = True
+    use_xs = os.environ.get("MVOC_XS", "1") != "0"  # MVOC_XS=0: A/B against the tiled GEMM (diagnostics)
 
     def __call__(self, x, **kw):
         if self._xs_ok(x, kw):
             if self.wp is None:
-                self.wp = pack_xs_weights(self.w)
-            return ops.xs_linear(x, self.wp, self.w.shape[0], bias=self.b, n_store=self.n, **kw)
+                self.wp = pack_xs_weights(self.w, self.b)
+            return ops.xs_linear(x, self.wp, self.w.shape[0], n_store=self.n, **kw)
         return ops.linear(x, self.w, self.b, n_store=self.n, **kw)
 
     def fold_layernorm(self, gamma, beta, eps=1e-5):
@@ -177,9 +184,8 @@ class Linear:
             # rows normalised in registers, gamma on the weights, beta @ W^T + bias as the per-channel constant: no statistics
             # pass, no LayerNorm tensor, no row-sum correction
             if self.wp_ln is None:
-                self.wp_ln = pack_xs_weights(self.w_ln)
-            return ops.xs_linear(x, self.wp_ln, self.w_ln.shape[0], cvec=self.ln[1], normalize=True, eps=self.ln[2],
-                                 n_store=self.n, **kw)
+                self.wp_ln = pack_xs_weights(self.w_ln, self.ln[1])
+            return ops.xs_linear(x, self.wp_ln, self.w_ln.shape[0], normalize=True, eps=self.ln[2], n_store=self.n, **kw)
         stats = ops.row_stats(x, self.ln[2])  # one read of the rows; every n-tile of the GEMM shares it
         return ops.linear(x, self.w_ln, None, n_store=self.n, ln=self.ln + (stats,), **kw)
 

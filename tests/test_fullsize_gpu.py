@@ -74,7 +74,22 @@ def test_pnp_step_properties_full_size(eng):
         assert torch.equal(on[3], on[4])  # feature-injection step: CFG becomes a no-op (SURVEY B-5)
         pnp_utils.register_time_all(pipe, None, None)
         off = _fwd(eng, x, 981.0)
-        assert torch.equal(on[:3], off[:3])  # the hooks never write chunks 0..2
+        # the hooks never write chunks 0..2.  With the hooks off the temporal blocks of the finest level run the fused
+        # LN -> QKV -> attention kernel (an injecting step needs Q / K in memory for the blend and runs the kernel chain): the two
+        # agree to kernel-choice noise; with the fused kernel disabled the same kernels run and the chunks are bit-identical
+        d = (on[:3].float() - off[:3].float()).abs().max() / off.float().abs().max()
+        rel = (on[:3].float() - off[:3].float()).norm() / off[:3].float().norm()
+        assert d < 8e-3 and rel < 5e-3, (float(d), float(rel))
+        from mvoc_amd.unet import TransformerTemporalModel
+        TransformerTemporalModel.use_fused = False
+        try:
+            off_chain = _fwd(eng, x, 981.0)
+            pnp_utils.register_time_all(pipe, 981, masks)
+            on_chain = _fwd(eng, x, 981.0)
+            pnp_utils.register_time_all(pipe, None, None)
+            assert torch.equal(on_chain[:3], off_chain[:3])
+        finally:
+            TransformerTemporalModel.use_fused = True
         assert not torch.equal(off[3], off[4])
         # conv_out injection semantics at full size: rows of the output where both masks are 0 come from chunk 0 (bg),
         # rows where the last object's mask is 1 come from that object's chunk

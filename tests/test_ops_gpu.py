@@ -478,13 +478,18 @@ def test_xs_linear_exact(ops, k, n, m):
     r = torch.randint(-16, 17, (m, n), generator=g).half()
     ref = x.double() @ w.double().t() + b.double()
     assert ref.abs().max() < 2048
-    out = ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b))
+    wp = pack_xs_weights(dev(w), dev(b))
+    out = ops.xs_linear(dev(x), wp, n)
     assert torch.equal(out.cpu().double(), ref)
-    out = ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b), resid=dev(r))
+    out = ops.xs_linear(dev(x), wp, n, resid=dev(r))
     assert torch.equal(out.cpu().double(), ref + r.double())
     # a narrower store (padded weight rows) into a wider row pitch
     wide = torch.full((m, n + 64), 7.0, dtype=torch.float16, device="cuda")
-    ops.xs_linear(dev(x), pack_xs_weights(dev(w)), n, bias=dev(b), n_store=n - 24, out=wide[:, 8:8 + n - 24])
+    ops.xs_linear(dev(x), wp, n, n_store=n - 24, out=wide[:, 8:8 + n - 24])
+    rs = torch.zeros((m, n + 40), dtype=torch.float16, device="cuda")  # residual rows of another pitch, trimmed last tile
+    rs[:, 16:16 + n] = dev(r)
+    out = ops.xs_linear(dev(x), wp, n, n_store=n - 24, resid=rs[:, 16:16 + n - 24])
+    assert torch.equal(out.cpu().double(), (ref + r.double())[:, :n - 24])
     assert torch.equal(wide[:, 8:8 + n - 24].cpu().double(), ref[:, :n - 24])
     assert (wide[:, :8] == 7).all() and (wide[:, 8 + n - 24:] == 7).all()
 

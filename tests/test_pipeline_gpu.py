@@ -245,7 +245,8 @@ def test_dropin_drivers_end_to_end(tmp_path):
     assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
     # with a VAE (seeded weights of the real architecture) the drivers go frames -> latents -> frames like the reference:
     # the source clips are VAE-encoded (encode_vae_video), results are decoded and written as gif + png (composite.py:217-224)
-    os.environ["MVOC_SYNTHETIC_VAE"] = "1"
+    # ... and with CLIP towers (seeded ViT-H/14 weights) the conditioning frames go through the batched vision tower
+    os.environ["MVOC_SYNTHETIC_VAE"] = os.environ["MVOC_SYNTHETIC_CLIP"] = "1"
     try:
         tmpl3 = OmegaConf.load(os.path.join(REPO, "tests", "data", "inversion_template.yaml"))
         tmpl3.data_dir = str(data)
@@ -255,7 +256,7 @@ def test_dropin_drivers_end_to_end(tmp_path):
         assert (data / "inversions_vae" / "i2vgen-xl" / "clipA" / "ddim_reconstruction.gif").exists()
         composite.main(ct, [dict(centry, edited_video_name="out_frames")], torch.device("cuda:0"), synthetic=True)
     finally:
-        del os.environ["MVOC_SYNTHETIC_VAE"]
+        del os.environ["MVOC_SYNTHETIC_VAE"], os.environ["MVOC_SYNTHETIC_CLIP"]
     fr = data / "Results" / "T" / "i2vgen-xl" / "clipA" / "out_frames" / sub[0]
     assert sorted(os.listdir(fr)) == ["video.gif"] + [f"video_{i:05d}.png" for i in range(4)]
     assert Image.open(fr / "video_00000.png").size == (64, 64)
