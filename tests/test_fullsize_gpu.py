@@ -82,6 +82,7 @@ def test_pnp_step_properties_full_size(eng):
         assert d < 8e-3 and rel < 5e-3, (float(d), float(rel))
         from mvoc_amd.unet import TransformerTemporalModel
         TransformerTemporalModel.use_fused = False
+        eng.prune_dead_chunks = False  # (an injecting conv_out step otherwise runs on the 3 source chunks only: other tiles)
         try:
             off_chain = _fwd(eng, x, 981.0)
             pnp_utils.register_time_all(pipe, 981, masks)
@@ -90,6 +91,7 @@ def test_pnp_step_properties_full_size(eng):
             assert torch.equal(on_chain[:3], off_chain[:3])
         finally:
             TransformerTemporalModel.use_fused = True
+            eng.prune_dead_chunks = True
         assert not torch.equal(off[3], off[4])
         # conv_out injection semantics at full size: rows of the output where both masks are 0 come from chunk 0 (bg),
         # rows where the last object's mask is 1 come from that object's chunk

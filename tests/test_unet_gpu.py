@@ -87,6 +87,24 @@ def test_g7_pnp_against_reference_golden(golden_dir):
         _close(out, torch.from_numpy(g["pnp_out_" + tag]), "g7 pnp " + tag)
         if tt == 981:  # feature-injection steps: chunks 3 and 4 leave conv_out identical (SURVEY B-5)
             assert torch.equal(out[3], out[4])
+            # ... and nothing computed FOR them reaches the output: the engine runs such a step on the source chunks only
+            # (prune_dead_chunks).  Against the full batch-of-5 evaluation of the same step: the destination chunks are the same
+            # blend of the source chunks; the source chunks agree to the accumulation-order noise of another row count
+            eng.prune_dead_chunks = False
+            try:
+                full = eng.forward_ext(t("sample"), tt, t("fps"), t("image_latents_first"), t("image_latents"),
+                                       t("image_embeddings"), t("encoder_hidden_states"))[0]
+            finally:
+                eng.prune_dead_chunks = True
+            _close(full, torch.from_numpy(g["pnp_out_" + tag]), "g7 pnp t981 (all five chunks computed)")
+            assert torch.equal(full[3], full[4])
+            rel = float((out.float() - full.float()).norm() / full.float().norm())
+            assert rel < 1e-3, rel
+            mb0 = torch.stack([m[1][0, 0] for m in masks]).cuda()  # [nobj, F, h, w] bool
+            keep_bg = (~mb0.any(0))[None].expand(out.shape[1], -1, -1, -1)
+            assert torch.equal(out[3][keep_bg], out[0][keep_bg])
+            last = mb0[-1][None].expand(out.shape[1], -1, -1, -1)
+            assert torch.equal(out[3][last], out[len(masks)][last])
 
 
 @pytest.mark.parametrize("b,f,h,w,mfg", [(1, 3, 8, 8, False), (2, 2, 10, 6, False), (1, 5, 12, 9, True), (1, 8, 8, 8, False),
