@@ -561,6 +561,46 @@ def test_xs_linear_layernorm_fold(ops, k, n, m):
     assert rel_l2(out, old) < 2.5e-3, rel_l2(out, old)
 
 
+@pytest.mark.parametrize("n,mode", [(320, "resid"), (960, "ln"), (2560, "geglu"), (320, "silu")])
+def test_xs_linear_two_row_groups(ops, n, mode):
+    """m >= 131072 rows at K = 320 selects the 64-rows-per-wave form (256-row blocks, one residual buffer per wave refilled
+    after the epilogue): exact-integer answers for the plain / residual forms, the tiled GEMM of this library for the others;
+    the row count is ragged so the last block carries clamped rows"""
+    from mvoc_amd._ffi import ACT_GEGLU, ACT_NONE, ACT_SILU
+    from mvoc_amd.unet import Linear, pack_geglu, pack_xs_weights
+    k, m = 320, 131072 + 77
+    g = torch.Generator(device="cuda").manual_seed(n)
+    if mode == "resid":
+        x = torch.randint(-3, 4, (m, k), generator=g, device="cuda").half()
+        w = torch.randint(-2, 3, (n, k), generator=g, device="cuda").half()
+        b = torch.randint(-8, 9, (n,), generator=g, device="cuda").half()
+        r = torch.randint(-16, 17, (m, n), generator=g, device="cuda").half()
+        ref = x.float() @ w.float().t() + b.float()  # exact in fp32: |sum| < 2^11
+        wp = pack_xs_weights(w, b)
+        assert torch.equal(ops.xs_linear(x, wp, n).float(), ref)
+        assert torch.equal(ops.xs_linear(x, wp, n, resid=r).float(), ref + r.float())
+        return
+    x = (torch.randn(m, k, generator=g, device="cuda") * 1.5 + 0.2).half()
+    w = (torch.randn(n, k, generator=g, device="cuda") / math.sqrt(k)).half()
+    b = (0.2 * torch.randn(n, generator=g, device="cuda")).half()
+    gm, bt = (1 + 0.3 * torch.randn(k, generator=g, device="cuda")).half(), (0.3 * torch.randn(k, generator=g, device="cuda")).half()
+    if mode == "geglu":
+        w, b = pack_geglu(w, b)
+    lin = Linear(w, b)
+    if mode != "silu":
+        lin.fold_layernorm(gm, bt)
+    kw = {"act": {"ln": ACT_NONE, "geglu": ACT_GEGLU, "silu": ACT_SILU}[mode]}
+    call = (lambda: lin(x, resid=x, **kw)) if mode == "silu" else (lambda: lin.call_ln(x, (gm, bt), **kw))
+    out = call()
+    Linear.use_xs = False
+    try:
+        old = call()
+    finally:
+        Linear.use_xs = True
+    assert rel_l2(out, old) < 2.5e-3, rel_l2(out, old)
+    assert (out.float() - old.float()).abs().max() < 3e-2
+
+
 def test_xs_linear_refuses(ops):
     from mvoc_amd.unet import pack_xs_weights
     x = torch.zeros(64, 96, dtype=torch.float16, device="cuda")
