@@ -120,7 +120,19 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
   const int S = 2 * RG, R = p.resid ? 2 * RG : 0;
   constexpr bool GEGLU = ACT == MVOC_ACT_GEGLU;
   constexpr bool geglu = GEGLU;
+  constexpr int PW_LO = NP / NW, PW_HI = (NP + NW - 1) / NW;  // pieces per stage of the waves without / with a remainder piece
   auto wait_stage = [&](int st) {  // DMA(st) has landed
+    if (st >= 2 && st + 1 < T) {
+      // steady state: the count is one of two compile-time constants per kernel variant (no dispatch tree on the stage's path)
+      if (geglu) {
+        if (pw == PW_HI) xs_wait<PW_HI + 2 * RG>(); else xs_wait<PW_LO + 2 * RG>();
+      } else if (p.resid) {
+        if (pw == PW_HI) xs_wait<PW_HI + 8 * RG>(); else xs_wait<PW_LO + 8 * RG>();
+      } else {
+        if (pw == PW_HI) xs_wait<PW_HI + 4 * RG>(); else xs_wait<PW_LO + 4 * RG>();
+      }
+      return;
+    }
     const int dma_next = st + 1 < T ? pw : 0;
     int n;
     if (st == 0) n = dma_next;

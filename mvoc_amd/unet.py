@@ -341,6 +341,7 @@ class ResnetBlock2D(Hookable):
         self.conv1_w, self.conv1_b = pack_conv3x3(g(".conv1.weight")), g(".conv1.bias")
         self.conv2_w, self.conv2_b = pack_conv3x3(g(".conv2.weight")), g(".conv2.bias")
         self.time_emb_proj = Linear(g(".time_emb_proj.weight"), g(".time_emb_proj.bias"))
+        self.tslice = None  # (column offset, width) in the engine's batched time projection
         self.cout = self.conv1_b.shape[0]
         self.conv_shortcut = None
         if prefix + ".conv_shortcut.weight" in sd:
@@ -352,7 +353,10 @@ class ResnetBlock2D(Hookable):
         hw, nimg = H * W, B * F
         h = ops.groupnorm(x, *self.norm1, x2=skip, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5,
                           silu=True)
-        tproj = self.time_emb_proj(temb_act)  # [B, Cout]; identical for all frames of a sample
+        if eng._tall is not None and self.tslice is not None:
+            tproj = eng._tall[:, self.tslice[0]:self.tslice[0] + self.tslice[1]]  # [B, Cout] columns of the batched projection
+        else:
+            tproj = self.time_emb_proj(temb_act)  # [B, Cout]; identical for all frames of a sample
         h, _, _ = ops.conv3x3(h, self.conv1_w, self.conv1_b, nimg=nimg, h=H, wd=W, rowadd=tproj, rowadd_div=F * hw,
                               n_store=self.cout)
         h = ops.groupnorm(h, *self.norm2, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5, silu=True)
@@ -600,6 +604,16 @@ class I2VGenXLUNet:
             self.up_blocks.append(b)
         self.conv_norm_out = (f16("conv_norm_out.weight"), f16("conv_norm_out.bias"))
         self.conv_out = ConvOut(sd["conv_out.weight"], sd["conv_out.bias"])
+        # every resnet's time_emb_proj (pnp_utils.py:924-931: a [B, 1280] x [1280, Cout] linear per resnet, 26 launches of
+        # M = B rows per forward at 2 % MFMA utilisation) as ONE linear over the concatenated output channels, once per step
+        rns = [rn for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks) for rn in blk.resnets]
+        off = 0
+        for rn in rns:
+            rn.tslice = (off, rn.cout)
+            off += rn.cout
+        self.time_proj_all = Linear(torch.cat([rn.time_emb_proj.w[:rn.cout] for rn in rns]),
+                                    torch.cat([rn.time_emb_proj.b[:rn.cout] for rn in rns]))
+        self._tall = None
         self._loaded = True
 
     # ---- PnP helpers ------------------------------------------------------------------------------
@@ -862,6 +876,7 @@ class I2VGenXLUNet:
         up_factor = 2 ** self.num_upsamplers
         forward_upsample_size = any(s % up_factor != 0 for s in (H, W))
         temb_act = self._embeddings(timestep, fps, B)
+        self._tall = self.time_proj_all(temb_act)
         sh = self.shard
         if conditioning is None:
             conditioning = self._conditioning((B, C, F, H, W), image_latents_first, image_latents, image_embeddings,
