@@ -262,6 +262,70 @@ def test_dropin_drivers_end_to_end(tmp_path):
     assert Image.open(fr / "video_00000.png").size == (64, 64)
 
 
+def test_composite_py_under_torchrun_two_ranks(tmp_path):
+    """`scripts/run_group_composition.sh NGPU=2`'s launch: composite.py under torch.distributed.run, two ranks, the group's
+    entries dealt round-robin (BASELINE configs[4]: one composition per GPU, no collectives).  On this one-GPU box both ranks
+    share the device (MVOC_ALLOW_GPU_SHARING=1); each must write exactly its own entry's result"""
+    import subprocess
+    from PIL import Image
+    sys.path[:0] = [os.path.join(REPO, "i2vgen-xl"), REPO]
+    for m in ("utils", "pnp_utils", "inverse", "composite", "pipelines", "pipelines.pipeline_i2vgen_xl"):
+        sys.modules.pop(m, None)
+    import inverse
+    from mvoc_amd.config import OmegaConf
+    data = tmp_path
+    rng = np.random.default_rng(1)
+    for name in ("clipA", "clipB"):
+        d = data / "demo" / name / name
+        d.mkdir(parents=True)
+        for i in range(4):
+            Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / f"{i:05d}.png")
+        (d / "edited_first_frame").mkdir()
+        Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(d / "edited_first_frame" / "00000.png")
+        for mname in ("m1", "m2"):
+            md = data / "demo" / name / mname
+            md.mkdir()
+            for i in range(4):
+                m = np.zeros((64, 64), np.uint8)
+                m[8 + 4 * i:40 + 4 * i, 16:48] = 255
+                Image.fromarray(m).save(md / f"{i:05d}.png")
+    tmpl = OmegaConf.load(os.path.join(REPO, "tests", "data", "inversion_template.yaml"))
+    tmpl.data_dir = str(data)
+    entries = [{"active": True, "force_recompute_latents": True, "video_name": n, "video_dir": str(data / "demo" / n), "image_size": [64, 64],
+                "n_frames": 4, "recon_config": {"enable_recon": False}} for n in ("clipA", "clipB")]
+    inverse.main(tmpl, entries, torch.device("cuda:0"), synthetic=True)
+    torch.cuda.empty_cache()
+    tpl = open(os.path.join(REPO, "tests", "data", "composite_template.yaml")).read().replace("REPLACED_BY_TEST", str(data))
+    (data / "composite_template.yaml").write_text(tpl)
+    base = {"active": True, "task_name": "T", "image_size": [64, 64], "editing_prompt": "a b", "ddim_init_latents_t_idx": 0,
+            "pnp_f_t": 0.2, "pnp_spatial_attn_t": 1.0, "pnp_temp_attn_t": 1.0, "random_noise_ratio": 0.0,
+            "obj_mask_path": ["demo/clipA/m1", "demo/clipA/m2"], "obj_width_height": [[64, 64], [64, 64]],
+            "obj_ddim_latents_path": ["inversions/i2vgen-xl/clipA/ddim_latents", "inversions/i2vgen-xl/clipB/ddim_latents"],
+            "edited_contorl_frame_path": ["demo/clipA/clipA", "demo/clipB/clipB"], "fusion_step": [0, 1]}
+    group = []
+    for k, (main, bg) in enumerate((("clipA", "clipB"), ("clipB", "clipA"))):
+        group.append(dict(base, video_name=main, edited_video_name=f"out{k}",
+                          edited_first_frame_path=f"demo/{main}/{main}/edited_first_frame/00000.png",
+                          bg_ddim_latents_path=f"inversions/i2vgen-xl/{bg}/ddim_latents",
+                          edited_contorl_frame_path_main=f"demo/{main}/{main}", edited_contorl_frame_path_background=f"demo/{bg}/{bg}"))
+    (data / "group.json").write_text(json.dumps(group))
+    env = dict(os.environ, MVOC_ALLOW_GPU_SHARING="1", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(REPO, "i2vgen-xl", "composite.py"), "--template_config",
+           str(data / "composite_template.yaml"), "--configs_json", str(data / "group.json"), "--synthetic"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=os.path.join(REPO, "i2vgen-xl"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    for k, main in enumerate(("clipA", "clipB")):
+        root = data / "Results" / "T" / "i2vgen-xl" / main / f"out{k}"
+        sub = os.listdir(root)
+        assert len(sub) == 1
+        lat = torch.load(root / sub[0] / "video_latents.pt")
+        assert tuple(lat.shape) == (1, 4, 4, 8, 8) and torch.isfinite(lat.float()).all()
+    # each entry was handled by exactly one rank (round-robin: entry k -> rank k)
+    log = r.stdout + r.stderr
+    assert log.count("out0") >= 1 and log.count("out1") >= 1
+
+
 def test_invert_many_matches_separate_inversions(tmp_path):
     """batched inversion of three clips (UNet batch 3) == three inversions at batch 1: same files, same return values up to
     the GEMM-tile / accumulation-order noise of a different batch size (5 steps: <= 3e-2 like the loop-vs-oracle tests);
