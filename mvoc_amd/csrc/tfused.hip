@@ -166,11 +166,25 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
   if constexpr (PP) prefetch(0);
   // one weight stage: acc += (32 weight rows) x (this wave's 32 activation rows); w_rows: weights are the row operand.
   //     bar_M ; MFMAs(stage) ; wait(stage+1 landed) ; bar_E ; first reads of stage+1 ; issue stage+3   | caller: epilogue(stage)
-  auto run_stage = [&](f32x16& acc, bool w_rows) {
+  // vmcnt retires in issue order and counts stores too: the wait for DMA(stage) must allow the output stores issued after it (the
+  // previous head's: 2 after each value tile) to stay in flight, or the first stages of a head wait for their acknowledgement and
+  // for part of the next stage's DMA.  `extra` = those stores (position in the head: v1 -> 2, next q0 -> 4, next k0 -> 2); a wave
+  // whose lanes are all past the last pixel issues none and keeps the plain count.
+  const bool wave_stores = __builtin_amdgcn_readfirstlane((int)__any(live));
+  auto run_stage = [&](f32x16& acc, bool w_rows, int extra) {
     if constexpr (!PP) {
       // one wave per SIMD, one barrier per stage: stage landed for every wave (and stage-1's readers are done) -> refill the
       // slot of stage-1 with stage+2, multiply, then the caller's epilogue; the CU's other block fills the gaps
-      wait_stage(stage, NS - 2);
+      if constexpr (NK % NW == 0) {
+        constexpr int PWC = NK / NW;
+        if (stage + 1 < T && extra && wave_stores) {
+          if (extra == 2) tf_wait<PWC + 2>(); else tf_wait<PWC + 4>();
+        } else {
+          wait_stage(stage, NS - 2);
+        }
+      } else {
+        wait_stage(stage, NS - 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -227,11 +241,11 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
   };
 
   // a q or k tile: D[channel][row] = W' x^T, LayerNorm fix-up, fp16 -> the two k16 operand fragments of the 32 channels
-  auto proj_qk = [&](int nbase, half8_t (&pk)[2]) {
+  auto proj_qk = [&](int nbase, half8_t (&pk)[2], int extra) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    run_stage(acc, true);
+    run_stage(acc, true, extra);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = nbase + 8 * q + 4 * h;
@@ -249,8 +263,8 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       half8_t qp[2], kp[2];
-      proj_qk(hd * 64 + 32 * i, qp);
-      proj_qk(C + hd * 64 + 32 * i, kp);
+      proj_qk(hd * 64 + 32 * i, qp, (i == 0 && hd > 0) ? 4 : 0);
+      proj_qk(C + hd * 64 + 32 * i, kp, (i == 0 && hd > 0) ? 2 : 0);
 #pragma unroll
       for (int s = 0; s < 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kp[s], qp[s], st, 0, 0, 0);
     }
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      run_stage(acc, false);
+      run_stage(acc, false, dt == 1 ? 2 : 0);
       const int n = 2 * C + hd * 64 + dt * 32 + r;  // this lane's value channel
       const float cv = lnc[n];
       half8_t vp[2];
