@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in rows[marks[-2] + 1:marks[-1]]:
         if "splitk_reduce" in r["Kernel_Name"]:      # second kernel of a split-K call: its bytes belong to that call
             tot += float(r["Counter_Value"])
-        elif "gemm" in r["Kernel_Name"]:              # one row per mvoc_gemm_f16 call = one "launch" of bench.py's roofline leg
+        elif "gemm" in r["Kernel_Name"] or "xslin_kernel" in r["Kernel_Name"]:  # one row per mvoc_gemm_f16 / mvoc_xs_linear_f16 call = one "launch" of bench.py's roofline leg
             tot += float(r["Counter_Value"]); n += 1
     res[c] = {"sum_kb": tot, "launches": n}
 fetch = res["FETCH_SIZE"]["sum_kb"] * 1024 * 2   # gfx950: FETCH_SIZE reports half of a wide coalesced read stream
@@ -37,7 +37,7 @@ try:
     digest = open("mvoc_amd/libmvoc_hip.so.stamp").read().strip()
 except OSError:
     digest = None
-j = {"kernel": "implicit-GEMM family (gemm_glds_kernel / gemm_kernel / gemm_pp_kernel instantiations + splitk_reduce_kernel)",
+j = {"kernel": "implicit-GEMM family (gemm_glds_kernel / gemm_kernel / gemm_pp_kernel / xslin_kernel instantiations + splitk_reduce_kernel)",
      "steps": steps, "mix": "3 inversion : 1 composition", "launches": n, "launches_per_step": n / steps,
      "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n, "hbm_bytes_per_launch": (fetch + write) / n,
      "lib_digest": digest,
