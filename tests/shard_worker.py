@@ -57,6 +57,7 @@ def unet(out_dir, which):
         block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
         attention_head_dim=64, transformer_in_heads=2, context_pool=8)
     eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+    eng.prune_dead_chunks = False  # (frame-sharded forwards compute every chunk: compare like with like)
     report = {"rank": rank}
 
     def inputs(B, F, h, w, seed):
@@ -180,6 +181,7 @@ def rccl_native(out_dir):
     cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
                      attention_head_dim=64, transformer_in_heads=2, context_pool=8)
     eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+    eng.prune_dead_chunks = False  # (frame-sharded forwards compute every chunk: compare like with like)
     r = lambda *s_: torch.randn(*s_, generator=g).half().to(dev)
     inp = (r(1, 4, 4, 16, 16), torch.tensor([500.0]).to(dev), torch.full((1,), 8.0).to(dev), r(1, 4, 4, 16, 16), r(1, 4, 4, 16, 16),
            r(1, 4, 64), r(1, 7, 64))
