@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
   constexpr int NP = NK + 1;            // pieces (1 KB) per stage: NK weight fragments + the constants
   constexpr int STAGE = NP * 1024;
   constexpr int K = NK * 16;
-  constexpr int RBUF = RG == 1 ? 4096 : 4096;  // per-wave residual tiles: RG 1: two parities x 2 KB; RG 2: one x 4 KB
+  constexpr int RBUF = 4096;            // per-wave residual tiles: RG 1: two parities x 2 KB; RG 2: one buffer of 4 KB
   // ring | per-wave residual tiles: everything the loop reads arrives by LDS-DMA, so no compiler-managed vector-memory load sits
   // beside the in-flight DMA (hipcc drains vmcnt to 0 for those) and every wait below is an exact count
   __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE + NW * RBUF];
