@@ -27,7 +27,8 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip"
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/mvoc_hip.h"]:
+    # sources only (.hip / .h): objects and their stamps live in the same directory and must not feed the digest
+    for f in sorted(x for x in os.listdir(CSRC) if x.endswith((".hip", ".h"))) + ["../../include/mvoc_hip.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
