@@ -30,6 +30,13 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP16_TFLOPS = 2500.0  # dense MFMA fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0     # HBM3E, same guide
+
+
+def _rate(fam, name, div):
+    """work (flops or bytes) per second of one kernel family, scaled by `div` (1e9 with ms -> T/s, 1e6 -> G/s)"""
+    f = fam.get(name)
+    return f["work"] / max(f["ms"], 1e-9) / div if f and f["ms"] > 0 else 0.0
 
 
 def parse():
@@ -291,10 +298,21 @@ def roofline_leg(job, steps):
         "algorithmic_tflop_all_steps": round(alg / 1e12, 2),
         "by_family_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         "by_family_launches": {k: int(v["launches"]) for k, v in fam.items()},
-        "flash_attn_tflops": round(fam["flash_attn"]["work"] / max(fam["flash_attn"]["ms"], 1e-9) / 1e9, 2),
-        "temporal_attn_gbps": round(fam["temporal_attn"]["work"] / max(fam["temporal_attn"]["ms"], 1e-9) / 1e6, 1),
-        "groupnorm_gbps": round(fam["groupnorm"]["work"] / max(fam["groupnorm"]["ms"], 1e-9) / 1e6, 1),
-        "pnp_gbps": round(fam["pnp"]["work"] / max(fam["pnp"]["ms"], 1e-9) / 1e6, 1),
+        "flash_attn_tflops": round(_rate(fam, "flash_attn", 1e9), 2),
+        "temporal_fused_tflops": round(_rate(fam, "temporal_fused", 1e9), 2),
+        "temporal_attn_gbps": round(_rate(fam, "temporal_attn", 1e6), 1),
+        "groupnorm_gbps": round(_rate(fam, "groupnorm", 1e6), 1),
+        "pnp_gbps": round(_rate(fam, "pnp", 1e6), 1),
+        # every family against ITS roofline: MFMA-bound families vs the dense fp16 peak, the rest vs the HBM peak
+        "family_roofline_frac": {
+            "gemm": round(achieved / PEAK_FP16_TFLOPS, 4),
+            "flash_attn": round(_rate(fam, "flash_attn", 1e9) / PEAK_FP16_TFLOPS, 4),
+            "temporal_fused": round(_rate(fam, "temporal_fused", 1e9) / PEAK_FP16_TFLOPS, 4),
+            "temporal_attn": round(_rate(fam, "temporal_attn", 1e6) / PEAK_HBM_GBPS, 4),
+            "groupnorm": round(_rate(fam, "groupnorm", 1e6) / PEAK_HBM_GBPS, 4),
+            "layernorm": round(_rate(fam, "layernorm", 1e6) / PEAK_HBM_GBPS, 4),
+            "pnp": round(_rate(fam, "pnp", 1e6) / PEAK_HBM_GBPS, 4),
+        },
         "note": "HIP events around every launch of an eager repeat of the timed steps; achieved = sum(2*m*n*k) / sum(duration)",
     }
 

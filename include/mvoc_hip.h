@@ -331,7 +331,8 @@ int mvoc_alltoall_frames(void* comm, const void* send, void* recv, size_t bytes_
  * Per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg).
  * ------------------------------------------------------------------------------------------- */
 enum { MVOC_FAM_GEMM = 0, MVOC_FAM_FLASH = 1, MVOC_FAM_TATTN = 2, MVOC_FAM_GN = 3, MVOC_FAM_LN = 4, MVOC_FAM_PNP = 5,
-       MVOC_FAM_MISC = 6, MVOC_FAM_COUNT = 7 };
+       MVOC_FAM_MISC = 6, MVOC_FAM_TFUSED = 7, MVOC_FAM_COUNT = 8 };
+/* work unit per family: flops for GEMM / FLASH / TFUSED (MFMA-bound), bytes for the others (HBM-bound) */
 int mvoc_prof_enable(int on);                  /* 1: bracket every launch with hipEvents (not capture-safe) */
 int mvoc_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_or_bytes_per_family);
 int mvoc_prof_reset(void);

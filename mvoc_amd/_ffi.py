@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MVOC_HIP_LIB") or os.path.join(_HERE, "libmvoc_hip.so
 
 A_PLAIN, A_CONV3X3, A_TEMPORAL3 = 0, 1, 2
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_GELU = 0, 1, 2, 3
-FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "pnp", "misc")
+FAMILIES = ("gemm", "flash_attn", "temporal_attn", "groupnorm", "layernorm", "pnp", "misc", "temporal_fused")
 
 vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
 

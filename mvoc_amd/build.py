@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvoc_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "tfused.hip", "xslin.hip", "norm.hip", "pnp.hip", "stem.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "gemm8.hip", "attention.hip", "tfused.hip", "xslin.hip", "norm.hip", "pnp.hip", "stem.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LAB = os.environ.get("MVOC_BUILD_LAB") == "1"  # diagnostic library (in-kernel stamps / ablations): libmvoc_hip_lab.so
 if LAB:
@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # gemm: neutral for the 32-row-per-wave tiles (same speed, no accvgpr traffic), required by the 64-row-per-wave tiles
 # (160 / 128 accumulator registers + operands fit 256 unified registers only in this form -> 2 waves per SIMD).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "gemm_pp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "tfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "gemm8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "tfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "xslin.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

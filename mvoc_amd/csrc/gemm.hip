@@ -757,176 +757,6 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / same-size convolution with TAP REUSE.  The K loop of the kernels above is bound by the L2 -> LDS fill
-// rate, and the general gather stages the activation tile once per tap: nine times the same rows, shifted.  Here the K
-// steps run (ky, channel chunk, kx) with kx fastest and the three kx taps of a (ky, chunk) share ONE staged block of
-// BM + 2 consecutive source pixels (linear pixel index m0-1+(ky-1)*W .. m0+BM+(ky-1)*W: consecutive pixels are
-// consecutive rows of the channels-last source, across image rows too).  The kx tap of output pixel r reads staged row
-// r + kx; what the zero padding would have zeroed (x+kx-1 outside the row, y+ky-1 outside the image, rows past M) is
-// zeroed on the fragment (4 v_cndmask per ds_read_b128) from a 9-bit validity mask per output pixel.  Activation bytes
-// staged: 1/3 of the general path; the weight ring is unchanged (one BN x BKK tile per step).
-// ------------------------------------------------------------------------------------------------------------
-template <int WN, int WM, int TN, int TM, int BKK>
-__global__ __launch_bounds__(WN* WM * 64) void conv_dx_kernel(const GemmArgs p) {
-  constexpr int NCH = BKK / 8, RPI = 64 / NCH, NW = WN * WM, BN = WN * TN * 32, BM = WM * TM * 32, ROW = BKK * 2;
-#define MVOC_SWZ(row) (BKK == 64 ? (((row) >> 1) & 7) : (((row) >> 2) & 3))
-  constexpr int IW = BN / RPI, PW = (IW + NW - 1) / NW;
-  constexpr int AR = BM + 2;                  // staged pixels per (ky, chunk)
-  constexpr int IA = (AR + RPI - 1) / RPI, PA = (IA + NW - 1) / NW;
-  constexpr int WST = BN * ROW, AST = IA * 1024;
-  constexpr int EPI_BYTES = 32 * (TN * 64 + 16);
-  constexpr int RING = 2 * WST + 2 * AST;
-  constexpr int SMEM = RING > NW * EPI_BYTES ? RING : NW * EPI_BYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave / WM, wm = wave % WM;
-  const int r = lane & 31, h = lane >> 5;
-  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int n0 = (int)(logical % (unsigned)p.n_tiles) * BN;
-  const int m0 = (int)(logical / (unsigned)p.n_tiles) * BM;
-  const half_t* zsrc = reinterpret_cast<const half_t*>(&g_zero16);
-  const int lrow = lane / NCH, pos = lane % NCH;
-  const int Wimg = p.wsrc, Himg = p.hsrc;
-
-  const half_t* wrow[PW];
-  bool wok[PW];
-#pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    const int row = (wave + i * NW) * RPI + lrow;
-    wok[i] = row < BN && n0 + row < p.N;
-    wrow[i] = p.w + (size_t)(wok[i] ? n0 + row : 0) * p.K + (pos ^ MVOC_SWZ(row)) * 8;
-  }
-  int srow0[PA], cch[PA];  // staged row j -> source pixel m0 - 1 + j (before the ky shift), chunk offset in halfs
-  bool jok[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int j = (wave + i * NW) * RPI + lrow;
-    jok[i] = j < AR;
-    srow0[i] = m0 - 1 + j;
-    cch[i] = (pos ^ MVOC_SWZ(j)) * 8;
-  }
-  unsigned fm[TM];  // validity of the nine taps of this lane's output pixels
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = m0 + (wm * TM + j) * 32 + r;
-    unsigned mk = 0;
-    if (m < p.M) {
-      const int rem = m % (Himg * Wimg);
-      const int y = rem / Wimg, x = rem - y * Wimg;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-        if (iy >= 0 && ix >= 0 && iy < Himg && ix < Wimg) mk |= 1u << t;
-      }
-    }
-    fm[j] = mk;
-  }
-
-  auto issue_w = [&](int buf, int ky, int c0, int kx) {
-    char* base = smem + buf * WST;
-    const int wk = (ky * 3 + kx) * p.cin + c0;
-#pragma unroll
-    for (int i = 0; i < PW; ++i)
-      if (IW % NW == 0 || wave + i * NW < IW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wok[i] ? wrow[i] + wk : zsrc),
-                                         (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
-  };
-  auto issue_a = [&](int buf, int ky, int c0) {
-    char* base = smem + 2 * WST + buf * AST;
-    const bool second = c0 >= p.c1;
-    const half_t* sbase = second ? p.a2 : p.a;
-    const int ld = second ? p.lda2 : p.lda;
-    const int cbase = second ? c0 - p.c1 : c0;
-    const int shift = (ky - 1) * Wimg;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      if (!(IA % NW == 0 || wave + i * NW < IA)) continue;  // wave-uniform
-      const int srow = srow0[i] + shift;
-      const bool ok = jok[i] && srow >= 0 && srow < p.M;
-      const half_t* src = ok ? sbase + (size_t)srow * ld + (cbase + cch[i]) : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + (wave + i * NW) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = 9 * (p.cin / BKK);
-  const int swzw = MVOC_SWZ(r);
-  // issue-side position (the step whose weights are requested next) and the triple whose activations are requested next
-  int iky = 0, ic0 = 0, ikx = 0;
-  issue_a(0, 0, 0);
-  issue_w(0, 0, 0, 0);
-  int cky = 0, cc0 = 0, ckx = 0;  // compute-side position
-  int wcur = 0, acur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // step kt's weights (and, at kx == 0, its activation block) have landed; the other buffers are free
-    if (kt + 1 < nk) {
-      if (++ikx == 3) { ikx = 0; ic0 += BKK; if (ic0 >= p.cin) { ic0 = 0; ++iky; } }
-      issue_w(wcur ^ 1, iky, ic0, ikx);
-    }
-    if (ckx == 0) {  // first step of a triple: request the NEXT triple's activation block into the idle buffer
-      int nky = cky, nc0 = cc0 + BKK;
-      if (nc0 >= p.cin) { nc0 = 0; ++nky; }
-      if (nky < 3) issue_a(acur ^ 1, nky, nc0);
-    }
-    const char* wl = smem + wcur * WST + (wn * TN * 32 + r) * ROW;
-    const int tapbit = cky * 3 + ckx;
-    const int swza = MVOC_SWZ(r + ckx);
-    const char* al = smem + 2 * WST + acur * AST + (wm * TM * 32 + r + ckx) * ROW;
-    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < BKK / 16; ++s) {
-      half8_t wf[TN], af[TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 32 * ROW + ((2 * s + h) ^ swzw) * 16);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        af[j] = *reinterpret_cast<const half8_t*>(al + j * 32 * ROW + ((2 * s + h) ^ swza) * 16);
-        af[j] = ((fm[j] >> tapbit) & 1u) ? af[j] : zero8;
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i], af[j], acc[i][j], 0, 0, 0);
-    }
-    wcur ^= 1;
-    if (++ckx == 3) { ckx = 0; acur ^= 1; cc0 += BKK; if (cc0 >= p.cin) { cc0 = 0; ++cky; } }
-  }
-  if (p.epi_lds) {
-    __syncthreads();
-    gemm_epilogue_lds<WN, WM, TN, TM, false>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES, nullptr);
-    return;
-  }
-  gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
-#undef MVOC_SWZ
-}
-
-template <int WN, int WM, int TN, int TM, int BKK>
-int launch_conv_dx(const GemmArgs& a0, hipStream_t s) {
-  GemmArgs a = a0;
-  constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-  a.n_tiles = (a.N + BN - 1) / BN;
-  a.m_tiles = (a.M + BM - 1) / BM;
-  const long nblk = (long)a.n_tiles * a.m_tiles;
-  if (nblk <= 0 || nblk > 0x7fffffffL) {
-    mvoc_set_error("gemm: grid of %ld blocks", nblk);
-    return -2;
-  }
-  hipLaunchKernelGGL((conv_dx_kernel<WN, WM, TN, TM, BKK>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
-  return mvoc_check_launch("conv_dx_kernel");
-}
-
 // sums the split-K slabs in slice order (deterministic) and applies the GEMM epilogue; thread = 4 consecutive n of a row
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1051,7 +881,40 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                  -2, "gemm: LayerNorm folding needs the plain single-source direct-to-LDS path (k %% 64 == 0), no split-K");
   }
   int tile = d->tile;
-  int model_sk = 0;
+  int model_sk = 0, g8_sk = 0;
+  // ---- eight-phase tiles (gemm8.hip): 81 = 256 channels x 256 pixels per block, 82 = 320 x 256 ------------------------------
+  const int64_t rows_a = d->a_mode == MVOC_A_CONV3X3 ? (int64_t)d->nimg * d->hsrc * d->wsrc : d->m;
+  const int64_t lim = (int64_t)1 << 31;  // 32-bit MUBUF offsets, rows beyond the range read zeros
+  const bool g8_ok = glds_ok && a.epi_lds && !(d->ln_rowsum && !d->ln_stats) && (a.n_store % 8 == 0) &&
+                     rows_a * d->lda * 2 < lim && (d->a2 == nullptr || rows_a * d->lda2 * 2 < lim) &&
+                     (int64_t)d->n * d->k * 2 < lim;
+  if (tile == 0 && g8_ok && d->m >= 4096 && d->k >= 512 && !(d->n <= 640 && d->k <= 640)) {
+    // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
+    // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last
+    // tile of a row and CUs idle in the last wave of blocks (one block per CU).  The 320-wide form runs ~7 % below the 256-wide
+    // one per flop (its register file is full: accumulator copies in the loop).
+    auto eff = [&](int bx, double rate) {
+      const int64_t nt = (d->n + bx - 1) / bx, blocks = ((d->m + 255) / 256) * nt;
+      return (double)d->n / (double)(nt * bx) * (double)blocks / (double)(((blocks + 255) / 256) * 256) * rate;
+    };
+    const double e81 = eff(256, 1.0);
+    const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.93) : 0.0;
+    if (e81 >= 0.55 || e82 >= 0.55) {
+      tile = e82 > e81 ? 82 : 81;
+    } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
+      // deep K on a grid of 64..190 tiles (the 16x16 / 8x8 levels): K slices bring the grid to one block per CU; measured
+      // 1.2-1.4x over the split-K form of the 128-wide tiles (M = 4096 / 5120, K = 3840 .. 23040)
+      const int64_t blocks = ((d->m + 255) / 256) * ((d->n + 255) / 256);
+      if (blocks >= 64 && blocks < 190) {
+        for (int sk = (int)(256 / blocks) > 4 ? 4 : (int)(256 / blocks); sk >= 2; --sk)
+          if (d->k % (64 * sk) == 0 && (size_t)sk * d->m * d->n * 4 <= d->workspace_bytes) {
+            tile = 81;
+            g8_sk = sk;
+            break;
+          }
+      }
+    }
+  }
   if (tile == 0 && glds_ok) {
     const bool stats_precomputed = !(d->ln_rowsum && !d->ln_stats);
     if (d->k <= 640 && d->m > 2048 && stats_precomputed && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {
@@ -1101,8 +964,9 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
-    const int bm = tile == 14 || tile == 64 || tile == 66 || tile == 67 || tile == 77 || tile % 10 == 5 ? 256 : 128;
-    const int bn = tile == 66 ? 320 : (tile == 67 || tile == 77) ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
+    const bool t8 = tile == 81 || tile == 82 || tile == 83;
+    const int bm = t8 || tile == 14 || tile == 64 || tile == 66 || tile == 67 || tile % 10 == 5 ? 256 : 128;
+    const int bn = tile == 66 || tile == 82 ? 320 : (tile == 67 || tile == 81 || tile == 83) ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (model_sk > 0) {
@@ -1116,31 +980,22 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       a.ws = (float*)d->workspace;
     }
   }
-  // ---- persistent ping-pong kernel (gemm_pp.hip): tiles 91 (256 x 256) / 92 (320 x 256) -----------------------------------
   {
-    const bool pp_ok = d->k % 32 == 0 && d->cin % 32 == 0 && d->c1 % 32 == 0 && a.epi_lds &&
-                       (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin) && !(d->ln_rowsum && !d->ln_stats);
-    int pp = 0;
-    if (d->tile >= 91 && d->tile <= 95) {
-      MVOC_REQUIRE(pp_ok && !(d->tile == 92 && d->act == MVOC_ACT_GEGLU), -2,
-                   "gemm: tiles 91-95 need k, cin, c1 %% 32 == 0, 16-byte addressable outputs, row statistics (92: no GEGLU)");
-      // 93 / 94: split LDS-DMA issue; 95: MUBUF LDS-DMA (sources must span < 2 GB: 32-bit byte offsets)
-      pp = d->tile == 91 ? 256 : d->tile == 92 ? 320 : d->tile == 93 ? 2561 : d->tile == 94 ? 2562 : 2563;
-    }
-    if (pp) {
+    if (tile == 81 || tile == 82 || tile == 83) {  // 83: the 256-wide tile without retained Y0 fragments (tuning)
+      MVOC_REQUIRE(g8_ok && !(tile == 82 && d->act == MVOC_ACT_GEGLU), -2,
+                   "gemm: tiles 81 / 82 need k, cin, c1 %% 64 == 0, 16-byte addressable outputs, row statistics, operands < 2 GB "
+                   "(82: no GEGLU)");
       a.split_k = 1; a.k_per_split = (int)d->k; a.ws = nullptr;
-#ifdef MVOC_PP_LAB
-      if (const char* e = getenv("MVOC_PP_LAB")) {  // "bits,stamp-buffer address" (diagnostic builds only)
-        unsigned long long ptr = 0;
-        sscanf(e, "%d,%llu", &a.lab, &ptr);
-        a.stamps = (unsigned long long*)ptr;
+      if (g8_sk > 1) {  // the automatic choice for an under-filled grid
+        a.split_k = g8_sk; a.k_per_split = (int)(d->k / g8_sk); a.ws = (float*)d->workspace;
       }
-#endif
-      if (d->split_k > 1 && d->workspace && d->act != MVOC_ACT_GEGLU && !d->ln_rowsum && d->k % (32 * d->split_k) == 0 &&
-          (size_t)d->split_k * d->m * d->n * 4 <= d->workspace_bytes) {
-        a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
+      if (d->tile != 0) {  // forced tile: honour a forced split too
+        if (d->split_k > 1 && d->workspace && d->act != MVOC_ACT_GEGLU && !d->ln_rowsum && d->k % (64 * d->split_k) == 0 &&
+            (size_t)d->split_k * d->m * d->n * 4 <= d->workspace_bytes) {
+          a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
+        }
       }
-      const int rc = mvoc_launch_gemm_pp(a, pp, s);
+      const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : tile == 83 ? 2560 : 320, s);
       if (rc == 0 && a.split_k > 1) {
         const long nthr = (long)a.M * (a.N / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
@@ -1149,22 +1004,6 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       return rc;
     }
   }
-  // 3x3 / stride 1 / same-size convolutions: the tap-reuse kernel (no split-K form)
-  const bool dx_ok = glds_ok && d->a_mode == MVOC_A_CONV3X3 && d->stride <= 1 && !d->upsample && d->hsrc == d->hout &&
-                     d->wsrc == d->wout && d->act != MVOC_ACT_GEGLU && !d->ln_rowsum && a.split_k == 1;
-  // Measured (tools/gemm_bench.py, B = 5 shapes): within +-4 % of the general gather on every conv of the network, 34.1 ms
-  // vs 34.1 ms in total -- a third of the activation bytes does not move the step time, so the loop is not bound by
-  // staged bytes alone.  Selectable (tiles 111 / 112 / 164 / 166), not a default.
-  if (dx_ok && d->tile >= 100) {
-    switch (d->tile - 100) {
-      case 12: return launch_conv_dx<1, 4, 5, 1, 64>(a, s);
-      case 11: return launch_conv_dx<2, 2, 2, 2, 64>(a, s);
-      case 64: return launch_conv_dx<1, 4, 5, 2, 32>(a, s);
-      case 66: return launch_conv_dx<2, 4, 5, 2, 32>(a, s);
-      default: break;
-    }
-  }
-  MVOC_REQUIRE(d->tile < 100, -2, "gemm: tile %d (tap-reuse conv) needs a 3x3 stride-1 same-size conv, no split-K, tiles 111/112/164/166", d->tile);
   if (glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && !d->upsample && !(d->ln_rowsum && !d->ln_stats)) {
     switch (tile) {  // the tiles the selection above produces, in their single-source plain-linear form
       case 11: return launch_glds<2, 2, 2, 2, 2, 0, 64, 1>(a, s);

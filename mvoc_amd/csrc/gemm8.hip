@@ -1,0 +1,519 @@
+// Eight-phase implicit GEMM for gfx950: the large launches of the network (linear / 3x3 conv / temporal conv with at
+// least a chip's worth of 256-pixel tiles) run through this kernel.
+//
+//   out[m, n] = epilogue( sum_k A(m, k) * W[n, k] )      fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)
+//
+// Same math, operand conventions, gathers (PLAIN / CONV3X3 / TEMPORAL3, two sources, stride, folded upsample) and the same
+// fp16 rounding points in the epilogue as gemm.hip.  What differs is the structure around the MFMAs
+// (cdna_hip_programming.md, "The 256^2 8-phase template", re-derived here for an implicit-GEMM gather):
+//
+// * One 8-wave block per CU computes 256 pixels x BX output channels (BX = 256 or 320); wave (wr, wc) owns channels
+//   wr*BX/2 .. and pixels wc*64 ..: a 2 x 2 grid of QUADRANTS of (BX/4 channels) x (32 pixels), one quadrant per phase, 16 (20)
+//   MFMAs of 16x16x32 each.  Weights are the MFMA row operand: a lane ends up with 4 consecutive channels of one pixel.
+// * A K tile (64 deep) lives in LDS as four HALF-TILES in the order they are consumed: Yh0 (the pixel rows of every wave's
+//   quadrant column 0), Xh0 (weight rows of quadrant row 0 of both wave groups), Yh1, Xh1.  Phase 1 reads Yh0 + Xh0 into
+//   registers, phase 2 Yh1, phase 3 Xh1 (over Xh0's registers), phase 4 nothing (Y0's fragments are kept): a half-tile's LDS
+//   slot is dead one or two phases after it was read, and every phase restages exactly one slot by LDS-DMA
+//   (buffer_load ... lds, 1 KB per wave-instruction), THREE half-tiles ahead of the tile being multiplied.  The DMA stays in
+//   flight across the raw s_barriers; the only wait is one counted s_waitcnt vmcnt per K tile (phase 4).
+// * The two wave groups (wr = 0 / 1; one wave of each per SIMD) run the same program ONE BARRIER APART: while one group
+//   issues its 16 MFMAs the other does its fragment reads and DMA issue.
+// * LDS rows are 128 B (64 k), 16-byte chunk c of row r at position c ^ ((r >> 1) & 7): applied to the DMA's per-lane source
+//   offset and to the fragment read (conflict-free for the 16x16x32 operand read: 16 rows x one chunk per 16-lane group).
+// * LDS-DMA as MUBUF: one 32-bit byte offset per lane and staged row (recomputed only when the K position crosses a tap or
+//   the second source), the K advance in the scalar offset, rows that must read zeros (padding taps, rows past M or N)
+//   carry an offset beyond the resource's range -- the hardware range check returns zeros.  No per-issue vector ALU work.
+// * Epilogue: arithmetic in the accumulator layout, fp16 result parked in a wave-private LDS tile, read back as 16-byte row
+//   chunks, residual added, stored (same rounding points as gemm_epilogue_lds).
+#include "gemm_args.h"
+
+namespace {
+
+constexpr unsigned G8_OOB = 0x80000000u;  // >= num_records of every resource: the load returns zeros
+
+#define G8_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+template <int N>
+__device__ __forceinline__ void g8_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XT: 16-channel tiles per quadrant (4 -> 256 channels per block, 5 -> 320).
+// RETAIN: keep Y0's fragments in registers for phase 4 (16 VGPRs); otherwise phase 4 re-reads them and the Yh0 half-tiles
+//   rotate through THREE slots so that restaging tile t+2's Yh0 (phase 2 of tile t) never collides with that re-read.
+// YP: the four activation row offsets live in registers and are rebuilt at tap / source changes; otherwise they are formed
+//   at issue time from (row, tap mask) -- five VALU per piece, for the 320-wide tile whose register file is full.
+// UPS: nearest-upsampled conv source (row not affine in the tap): own instantiation, the hot kernels carry no such code.
+// AFF: the source row of a staged pixel is affine in its index (plain, temporal, and 3x3 stride-1 same-size convs:
+//   row = m + (ky - 1) W + (kx - 1), validity in the tap masks): ONE row register serves the four staged rows of a lane.
+template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
+  constexpr int XQ = XT * 16;            // channels per quadrant (and per wave group per X half-tile)
+  constexpr int XH = 2 * XQ;             // rows of an X half-tile
+  constexpr int BX = 4 * XQ;             // channels per block
+  constexpr int XB = XH * 128, YB = 128 * 128;
+  constexpr int NY0 = RETAIN ? 2 : 3;    // Yh0 slots
+  constexpr int KB = 2 * XB + YB;        // bytes of one K-tile buffer {Xh0, Yh1, Xh1}
+  constexpr int OX0 = 0, OY1 = XB, OX1 = XB + YB;
+  constexpr int OY0 = 2 * KB;            // Yh0 slots behind the two buffers
+  constexpr int SMEM = 2 * KB + NY0 * YB;
+  constexpr int XPC = XH / 8;            // 1 KB pieces per X half-tile: 16 / 20
+  constexpr int PXM = (XPC + 7) / 8;     // per wave, at most
+  static_assert(SMEM <= 163840, "LDS budget");
+  static_assert(YP || !UPS, "the upsample form keeps its offsets in registers");
+  static_assert(!(AFF && UPS), "an upsampled source is not affine");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = (int)(logical0 % (unsigned)p.split_k);
+  const unsigned logical = logical0 / (unsigned)p.split_k;
+  const int n0 = (int)(logical % (unsigned)p.n_tiles) * BX;
+  const int m0 = (int)(logical / (unsigned)p.n_tiles) * 256;
+  const int kbeg = slice * p.k_per_split;
+  const int nk = p.k_per_split / 64;
+  // X pieces of this wave per half-tile (wave-uniform): 2, or 3 / 2 for BX = 320
+  const int npx = XPC % 8 == 0 ? XPC / 8 : (XPC - wave + 7) / 8;
+
+  // ---- LDS-DMA lane geometry: piece j covers local rows 8 j .. 8 j + 7; lane = (row in piece, chunk position) -------------
+  const int lrow = lane >> 3, pos = lane & 7;
+  const int cch = (pos ^ ((4 * wave + (lrow >> 1)) & 7)) * 8;  // source chunk (halfs): swizzle of row 8 (wave + 8 q) + lrow
+  // weight side: one byte offset per staged row of X half 0 (half 1 = + XQ rows); the K advance lives in the scalar
+  // offset; rows >= N fall outside the resource (num_records = N K 2 bytes) and read zeros
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((size_t)p.N * p.K * 2), 0x00020000);
+  unsigned xoff[PXM];
+#pragma unroll
+  for (int q = 0; q < PXM; ++q) {
+    const int lr = 8 * (wave + 8 * q) + lrow;
+    const int row = n0 + (lr / XQ) * (2 * XQ) + (lr % XQ);
+    xoff[q] = (unsigned)(((size_t)row * p.K + cch) * 2);
+  }
+  const unsigned xh1 = (unsigned)XQ * (unsigned)p.K * 2u;  // byte distance of half 1's rows
+  int xso0 = kbeg * 2, xso1 = kbeg * 2;  // scalar byte offsets of the two X streams
+  // activation side: per staged row a source-row index for tap (0,0) and a mask of the taps inside the image (two 16-bit
+  // masks per register)
+  int rowoff[AFF ? 1 : 2][AFF ? 1 : 2];
+  unsigned vmask[2];  // [h]: q = 0 in bits 0..15, q = 1 in bits 16..31
+  unsigned yoff[YP ? 2 : 1][YP ? 2 : 1];
+  auto row_m = [&](int h, int q) {
+    const int lr = 8 * (wave + 8 * q) + lrow;
+    return m0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+  };
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    vmask[h] = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int m = row_m(h, q);
+      const bool live = m < p.M;
+      const int mm = live ? m : 0;
+      if constexpr (!AFF) rowoff[h][q] = mm;
+      if constexpr (YP) yoff[h][q] = G8_OOB;
+      unsigned mk = live ? 1u : 0u;
+      if (p.a_mode == MVOC_A_CONV3X3) {
+        const int hwout = p.hout * p.wout;
+        const int img = mm / hwout;
+        const int rem = mm - img * hwout;
+        const int oy = rem / p.wout;
+        const int y0 = oy * p.stride - p.pad, x0 = (rem - oy * p.wout) * p.stride - p.pad;
+        if constexpr (!AFF) rowoff[h][q] = (img * p.hsrc + y0) * p.wsrc + x0;
+        mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = y0 + t / 3, ix = x0 + t % 3;
+          if (live && iy >= 0 && ix >= 0 && iy < p.hup && ix < p.wup) mk |= 1u << t;
+        }
+      } else if (p.a_mode == MVOC_A_TEMPORAL3) {
+        const int f = (mm / p.hw) % p.frames;
+        mk = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (live && f + t - 1 >= 0 && f + t - 1 < p.frames) mk |= 1u << t;
+      }
+      vmask[h] |= mk << (16 * q);
+    }
+  }
+  if constexpr (AFF) rowoff[0][0] = row_m(0, 0) - (p.a_mode == MVOC_A_CONV3X3 ? p.wsrc + 1 : 0);
+  // K position of the NEXT activation tile to issue (both Y halves of a tile are issued from the same position): all scalar
+  int ytap = kbeg / p.cin;
+  int ych0 = kbeg - ytap * p.cin;
+  int yso = 0, yld2 = 0, ytaprows = 0;
+  bool yre = true;
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)G8_OOB, 0x00020000);
+
+  auto y_offset = [&](int h, int q) -> unsigned {
+    const bool ok = (vmask[h] >> (16 * q + ytap)) & 1u;
+    unsigned srow = (unsigned)((AFF ? rowoff[0][0] + h * 32 + q * 128 : rowoff[AFF ? 0 : h][AFF ? 0 : q]) + ytaprows);
+    if constexpr (UPS) {  // nearest-upsampled source: the row is not affine in the tap (three launches per forward)
+      const int ky = ytap / 3, kx = ytap - ky * 3;
+      const int m = min(row_m(h, q), p.M - 1);
+      const int hwout = p.hout * p.wout;
+      const int img = m / hwout;
+      const int rem = m - img * hwout;
+      const int oy = rem / p.wout;
+      const int iy = min((int)floorf((oy * p.stride - p.pad + ky) * p.ups_sh), p.hsrc - 1);
+      const int ix = min((int)floorf(((rem - oy * p.wout) * p.stride - p.pad + kx) * p.ups_sw), p.wsrc - 1);
+      srow = (unsigned)((img * p.hsrc + iy) * p.wsrc + ix);
+    }
+    const unsigned off = (unsigned)__umul24(srow, (unsigned)yld2) + (unsigned)(cch * 2);  // rows and pitches are < 2^24
+    return ok ? off : G8_OOB;
+  };
+  // new tap or new source (wave-uniform event, every cin / 64 or c1 / 64 K tiles)
+  auto y_prepare = [&]() {
+    if (!yre) return;
+    const bool second = ych0 >= p.c1;
+    yld2 = (second ? p.lda2 : p.lda) * 2;
+    ytaprows = 0;
+    if (p.a_mode == MVOC_A_CONV3X3) ytaprows = (ytap / 3) * p.wsrc + (ytap % 3);
+    else if (p.a_mode == MVOC_A_TEMPORAL3) ytaprows = (ytap - 1) * p.hw;
+    yso = (second ? ych0 - p.c1 : ych0) * 2;
+    rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.a2 : p.a), 0, (int)G8_OOB, 0x00020000);
+    if constexpr (YP) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) yoff[h][q] = y_offset(h, q);
+    }
+  };
+  auto y_advance = [&]() {
+    yso += 128;
+    ych0 += 64;
+    yre = ych0 == p.c1;
+    if (ych0 >= p.cin) { ych0 = 0; ++ytap; yre = true; }
+  };
+
+  const int wbase = wave * 1024;
+#define G8_LDS(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
+  // (half 1's offset is formed at issue time by an opaque add: loop-invariant, hipcc would otherwise keep PXM more registers)
+  auto x_off = [&](int h, int q) -> unsigned {
+    if (!h || YP) return xoff[q] + (h ? xh1 : 0u);
+    unsigned r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(xh1), "v"(xoff[q]));
+    return r;
+  };
+#define G8_ISSUE_X(h, base, so)                                                                                         \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < PXM; ++q) if (q < npx)                                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, G8_LDS((base) + wbase + q * 8192), 16, (int)x_off(h, q), so, 0, 0); \
+    so += 128;                                                                                                          \
+  } while (0)
+#define G8_ISSUE_Y(h, base)                                                                                             \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                       \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, G8_LDS((base) + wbase + q * 8192), 16,                           \
+                                                 (int)(YP ? yoff[YP ? h : 0][YP ? q : 0] : y_offset(h, q)), yso, 0, 0);                   \
+  } while (0)
+
+  // ---- fragment reads: lane reads row (l & 15) of a 16-row tile, chunk 4 s + (l >> 4) -----------------------------------
+  const int fr = lane & 15, fg = lane >> 4;
+  const int sw = fr >> 1;
+  const char* xr0 = smem + (wr * XQ + fr) * 128 + (fg ^ sw) * 16;        // k-step 0 / 1 of this lane's X rows
+  const char* xr1 = smem + (wr * XQ + fr) * 128 + ((4 + fg) ^ sw) * 16;
+  const char* yr0 = smem + (wc * 32 + fr) * 128 + (fg ^ sw) * 16;
+  const char* yr1 = smem + (wc * 32 + fr) * 128 + ((4 + fg) ^ sw) * 16;
+#define G8_LDP(ptr, off) (*reinterpret_cast<const half8_t*>((ptr) + (off)))
+
+  half8_t xf[XT][2], yf0[2][2], yf1s[RETAIN ? 2 : 1][2][2];
+  auto& yf1 = RETAIN ? yf1s[RETAIN ? 1 : 0] : yf0;  // !RETAIN: one fragment set serves Y0 and Y1 in turn
+  (void)yf1s;
+  f32x4 acc[2][2][XT][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < XT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define G8_RDX(off)                                             \
+  _Pragma("unroll") for (int i = 0; i < XT; ++i) {              \
+    xf[i][0] = G8_LDP(xr0, (off) + i * 2048);                   \
+    xf[i][1] = G8_LDP(xr1, (off) + i * 2048);                   \
+  }
+#define G8_RDY(dst, off)                                        \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {               \
+    dst[j][0] = G8_LDP(yr0, (off) + j * 2048);                  \
+    dst[j][1] = G8_LDP(yr1, (off) + j * 2048);                  \
+  }
+#define G8_MMA(A, B, YF)                                                                                              \
+  do {                                                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < XT; ++i)                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+            acc[A][B][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[i][s], YF[j][s], acc[A][B][i][j], 0, 0, 0);  \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
+  } while (0)
+
+  // in flight behind the per-tile wait: {Yh0, Xh0, Yh1} of the tile after next = 2 + npx + 2 LDS-DMA of this wave
+  auto wait_tile = [&]() {
+    if (XT == 5 && npx == 3) g8_wait_vm<7>(); else g8_wait_vm<6>();
+  };
+
+  // ---- prologue: K tile 0 landed, {Yh0, Xh0, Yh1} of tile 1 in flight ------------------------------------------------------
+  y_prepare();
+  G8_ISSUE_Y(0, OY0); G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_Y(1, OY1); G8_ISSUE_X(1, OX1, xso1);
+  y_advance();
+  if (nk > 1) {
+    y_prepare();
+    G8_ISSUE_Y(0, OY0 + YB); G8_ISSUE_X(0, KB + OX0, xso0); G8_ISSUE_Y(1, KB + OY1);
+    y_advance();
+    wait_tile();
+  } else {
+    g8_wait_vm<0>();
+  }
+  G8_BAR();
+  if (wr == 1) G8_BAR();  // group 1 falls one barrier behind
+
+  // Yh0 slots: RETAIN -> the tile's parity (static); otherwise three rotating byte offsets (scalar)
+  int y0a = 0, y0b = YB, y0c = 2 * YB;  // slot of tile t, t+1, t+2 (mod 3)
+
+  // One K tile = 4 phases; P = parity of the tile (static: every LDS offset is an immediate).  Phase j restages one
+  // half-tile: Xh1 of tile t+1 (the other buffer), then Yh0, Xh0, Yh1 of tile t+2 (RETAIN: Yh0's slot was read in phase 1 and
+  // those reads were waited for before phase 1's first barrier; Xh0 / Yh1 are two phases old; !RETAIN: Yh0 goes to the
+  // third slot).
+#define G8_KTILE(P, t)                                                                                 \
+  do {                                                                                                 \
+    /* ---- phase 1: (X0, Y0) ---- */                                                                  \
+    if constexpr (RETAIN) { G8_RDY(yf0, OY0 + (P) * YB); } else { G8_RDY(yf0, OY0 + y0a); }            \
+    asm volatile("" ::: "memory");                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    G8_RDX((P) * KB + OX0);                                                                            \
+    asm volatile("" ::: "memory");                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if ((t) + 1 < nk) G8_ISSUE_X(1, (1 - (P)) * KB + OX1, xso1);                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * XT) : "memory"); /* the four Y reads are back */    \
+    G8_BAR();                                                                                          \
+    G8_MMA(0, 0, yf0);                                                                                 \
+    G8_BAR();                                                                                          \
+    /* ---- phase 2: (X0, Y1) ---- */                                                                  \
+    G8_RDY(yf1, (P) * KB + OY1);                                                                       \
+    asm volatile("" ::: "memory");                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if ((t) + 2 < nk) {                                                                                \
+      y_prepare();                                                                                     \
+      if constexpr (RETAIN) { G8_ISSUE_Y(0, OY0 + (P) * YB); } else { G8_ISSUE_Y(0, OY0 + y0c); }      \
+    }                                                                                                  \
+    G8_BAR();                                                                                          \
+    G8_MMA(0, 1, yf1);                                                                                 \
+    G8_BAR();                                                                                          \
+    /* ---- phase 3: (X1, Y1) ---- */                                                                  \
+    G8_RDX((P) * KB + OX1);                                                                            \
+    asm volatile("" ::: "memory");                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    if ((t) + 2 < nk) G8_ISSUE_X(0, (P) * KB + OX0, xso0);                                             \
+    G8_BAR();                                                                                          \
+    G8_MMA(1, 1, yf1);                                                                                 \
+    G8_BAR();                                                                                          \
+    /* ---- phase 4: (X1, Y0) ---- */                                                                  \
+    if constexpr (!RETAIN) {                                                                           \
+      G8_RDY(yf0, OY0 + y0a);                                                                          \
+      asm volatile("" ::: "memory");                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
+    if ((t) + 2 < nk) {                                                                                \
+      G8_ISSUE_Y(1, (P) * KB + OY1);                                                                   \
+      y_advance();                                                                                     \
+      wait_tile();                                                                                     \
+    } else if ((t) + 2 == nk) {                                                                        \
+      g8_wait_vm<0>();                                                                                 \
+    }                                                                                                  \
+    G8_BAR();                                                                                          \
+    G8_MMA(1, 0, yf0);                                                                                 \
+    G8_BAR();                                                                                          \
+    if constexpr (!RETAIN) { const int r_ = y0a; y0a = y0b; y0b = y0c; y0c = r_; }                     \
+  } while (0)
+
+  int t = 0;
+#pragma unroll 1
+  for (; t + 1 < nk; t += 2) {
+    G8_KTILE(0, t);
+    G8_KTILE(1, t + 1);
+  }
+  if (t < nk) G8_KTILE(0, t);
+  if (wr == 0) G8_BAR();  // group 0's balancing barrier: every wave is out of the K loop, the ring is free
+
+  const int g = fg;  // lane owns channels nq + 4 g .. + 3 of pixel (lane & 15) per 16 x 16 tile
+  if (p.split_k > 1) {  // raw fp32 partials; bias / activation / residual happen in the reduce pass
+    float* slab = p.ws + (size_t)slice * p.M * p.N;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wr * XH + a * XQ + i * 16 + 4 * g;
+            const int m = m0 + wc * 64 + b * 32 + j * 16 + fr;
+            if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[a][b][i][j];
+          }
+    return;
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  const bool geglu = p.act == MVOC_ACT_GEGLU;
+  const bool use_ln = p.ln_s != nullptr;
+  const bool use_bias = p.bias && !use_ln;
+  constexpr int PITCH = XQ * 2 + 16;        // 144 / 176 B per pixel row of the wave's tile
+  char* epi = smem + wave * (64 * PITCH);
+  float ln_mu[2][2], ln_rs[2][2];
+  const half_t* ra[2][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wc * 64 + b * 32 + j * 16 + fr;
+      const int ms = m < p.M ? m : p.M - 1;
+      ln_mu[b][j] = 0.f; ln_rs[b][j] = 1.f;
+      if (use_ln) { ln_mu[b][j] = p.ln_stats[2 * (size_t)ms]; ln_rs[b][j] = p.ln_stats[2 * (size_t)ms + 1]; }
+      ra[b][j] = p.rowadd ? p.rowadd + (size_t)(ms / p.rowadd_div) * p.ld_rowadd : nullptr;
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {  // (fully unrolled: the accumulators must be indexed statically)
+    const int nq = n0 + wr * XH + a * XQ;  // first packed weight row of this pass
+    int nchunk, nbase;
+    if (geglu) {
+      if constexpr (XT == 4) {
+        // packed rows: blocks of 64 = 32 value rows then 32 gate rows -> tiles i = 0, 1 are values, i + 2 their gates
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int nh_ = nq + i * 16 + 4 * g;
+          const bool live = nh_ < p.N;
+          half4_t bh = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+          f32x4 sh = {0.f, 0.f, 0.f, 0.f}, sg = sh, ch = sh, cg = sh;
+          if (live && use_bias) {
+            bh = *reinterpret_cast<const half4_t*>(p.bias + nh_);
+            bg = *reinterpret_cast<const half4_t*>(p.bias + nh_ + 32);
+          }
+          if (live && use_ln) {
+            sh = *reinterpret_cast<const f32x4*>(p.ln_s + nh_);
+            sg = *reinterpret_cast<const f32x4*>(p.ln_s + nh_ + 32);
+            ch = *reinterpret_cast<const f32x4*>(p.ln_c + nh_);
+            cg = *reinterpret_cast<const f32x4*>(p.ln_c + nh_ + 32);
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              half4_t o = {0, 0, 0, 0};
+              if (live) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float av = acc[a][b][i][j][e], ag = acc[a][b][i + 2][j][e];
+                  const float hv = r16(use_ln ? ln_rs[b][j] * (av - ln_mu[b][j] * sh[e]) + ch[e] : av + (float)bh[e]);
+                  const float gv = r16(use_ln ? ln_rs[b][j] * (ag - ln_mu[b][j] * sg[e]) + cg[e] : ag + (float)bg[e]);
+                  o[e] = (half_t)(hv * r16(gelu_fast_f(gv)));
+                }
+              }
+              *reinterpret_cast<half4_t*>(epi + (b * 32 + j * 16 + fr) * PITCH + (i * 16 + 4 * g) * 2) = o;
+            }
+        }
+      }
+      nchunk = 4;
+      nbase = nq / 2;
+    } else {
+#pragma unroll
+      for (int i = 0; i < XT; ++i) {
+        const int n = nq + i * 16 + 4 * g;
+        const bool live = n < p.n_store;
+        half4_t b4 = {0, 0, 0, 0};
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, c4 = s4;
+        if (live && use_bias) b4 = *reinterpret_cast<const half4_t*>(p.bias + n);
+        if (live && use_ln) {
+          s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+          c4 = *reinterpret_cast<const f32x4*>(p.ln_c + n);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            half4_t o = {0, 0, 0, 0};
+            if (live) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = r16(use_ln ? ln_rs[b][j] * (acc[a][b][i][j][e] - ln_mu[b][j] * s4[e]) + c4[e] : acc[a][b][i][j][e] + (float)b4[e]);
+              if (ra[b][j]) {
+                const half4_t t4 = *reinterpret_cast<const half4_t*>(ra[b][j] + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
+              }
+              if (p.act == MVOC_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+              } else if (p.act == MVOC_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+            }
+            *reinterpret_cast<half4_t*>(epi + (b * 32 + j * 16 + fr) * PITCH + (i * 16 + 4 * g) * 2) = o;
+          }
+      }
+      nchunk = XT * 2;
+      nbase = nq;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (a wave's DS ops execute in order)
+    // read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row
+    const int total = 64 * nchunk;
+#pragma unroll 2
+    for (int idx = lane; idx < total; idx += 64) {
+      const int px = idx / nchunk, c = idx - px * nchunk;
+      const int m = m0 + wc * 64 + px, n = nbase + c * 8;
+      half8_t v = *reinterpret_cast<const half8_t*>(epi + px * PITCH + c * 16);
+      if (m < p.M && n < p.n_store) {
+        if (p.resid) {
+          const half8_t r8 = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
+        }
+        *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
+  }
+}
+
+template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
+int launch8(const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  constexpr int BX = XT * 64;
+  a.n_tiles = (a.N + BX - 1) / BX;
+  a.m_tiles = (a.M + 255) / 256;
+  const long nblk = (long)a.n_tiles * a.m_tiles * a.split_k;
+  if (nblk <= 0 || nblk > 0x7fffffffL) {
+    mvoc_set_error("gemm8: grid of %ld blocks", nblk);
+    return -2;
+  }
+  hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  return mvoc_check_launch("gemm8_kernel");
+}
+
+}  // namespace
+
+// bx = 256 or 320 output channels per block.  Preconditions (checked by the caller, gemm.hip): k, cin, c1 multiples of 64,
+// conv k == 9 cin, 16-byte addressable outputs (epi_lds), row statistics precomputed when a LayerNorm is folded in, GEGLU
+// only with bx = 256, every operand spanning < 2 GB (32-bit MUBUF offsets).
+int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
+  if (a.upsample) {  // (rare: the three upsampler convs of a forward) one form serves every width
+    if (bx == 256 || bx == 2560 || bx == 320) return launch8<4, true, true, true, false>(a, s);
+  } else {
+    const bool affine = a.a_mode != MVOC_A_CONV3X3 || (a.stride == 1 && a.pad == 1 && a.hsrc == a.hout && a.wsrc == a.wout);
+    if (bx == 256 || (bx == 320 && !affine)) return launch8<4, true, true, false, false>(a, s);
+    if (bx == 2560) return launch8<4, false, true, false, false>(a, s);
+    if (bx == 320) return launch8<5, false, false, false, true>(a, s);
+  }
+  mvoc_set_error("gemm8: unsupported tile width %d", bx);
+  return -1;
+}

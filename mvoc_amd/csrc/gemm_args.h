@@ -1,5 +1,5 @@
-// Argument block shared by the implicit-GEMM kernel families (gemm.hip: per-tile blocks; gemm_pp.hip: the persistent
-// ping-pong kernel).
+// Argument block shared by the implicit-GEMM kernel families (gemm.hip: the general tiles; gemm8.hip: the eight-phase
+// 256-pixel tiles).
 #pragma once
 #include "common.h"
 
@@ -26,11 +26,9 @@ struct GemmArgs {
   float ln_eps;
   int split_k, k_per_split;  // split-K: grid covers n_tiles*m_tiles*split_k; slice s accumulates k in [s*kps, (s+1)*kps)
   float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
-  int lab;                      // diagnostic builds only (MVOC_PP_LAB): bit 0 = no LDS-DMA in the K loop, bit 1 = all sources -> zero page
-  unsigned long long* stamps;   //   per-segment cycle sums of block 0 (waves 0 and 4): [2][8]
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 
 
-// persistent ping-pong kernel (gemm_pp.hip): bn = 256 or 320 output channels per tile, 256 pixels per tile
-int mvoc_launch_gemm_pp(const GemmArgs& a, int bn, hipStream_t s);
+// eight-phase kernel (gemm8.hip): bx = 256 or 320 output channels per block, 256 pixels per block
+int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s);

@@ -374,7 +374,7 @@ extern "C" int mvoc_temporal_qkv_attn_f16(const mvoc_tfused_desc* d, void* strea
   dim3 grid((unsigned)((d->hw + ppb - 1) / ppb), (unsigned)d->nsample);
   hipStream_t s = (hipStream_t)stream;
   const double rows = (double)d->nsample * d->frames * d->hw;
-  MvocProfScope prof(MVOC_FAM_TATTN, s, 2.0 * rows * 3.0 * d->c * d->c + 4.0 * rows * d->frames * d->c);
+  MvocProfScope prof(MVOC_FAM_TFUSED, s, 2.0 * rows * 3.0 * d->c * d->c + 4.0 * rows * d->frames * d->c);
   if (nw == 8) {
     if (d->c == 320) hipLaunchKernelGGL((tfused_kernel<20, 8>), grid, dim3(512), 0, s, a);
     else if (d->c == 128) hipLaunchKernelGGL((tfused_kernel<8, 8>), grid, dim3(512), 0, s, a);

@@ -278,15 +278,19 @@ class I2VGenXLPipeline:
         table, index = sched.coef_table(self.device, guidance_scale)
         # keyed by what the captured iteration bakes in (shapes, CFG layout, frame shard, graphs on/off) -- NOT by the
         # conditioning tensors' addresses: those change with every invert() / __call__()
-        key = ("stock", tuple(latents.shape), guidance_scale > 1, id(self.unet.shard), bool(self.use_graphs),
-               tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
-        st = self._graphs.get(key)
+        flags = self.unet.injection_flags()
+        if any(flags):  # eager mode raises on the batch layout; a cached graph would silently replay a clean iteration
+            raise RuntimeError("stock loop with PnP hooks armed: call register_time_all(pipe, None, None) first")
+        key = ("stock", tuple(latents.shape), guidance_scale > 1, getattr(self.unet, "shard_generation", 0) if self.unet.shard is not None else 0,
+               bool(self.use_graphs), flags, tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
+        st = self._graphs.pop(key, None)
         if st is None:
             if len(self._graphs) >= self.max_cached_graphs:  # each entry pins a UNet graph + its private activation pool
-                self._graphs.pop(next(iter(self._graphs)))
-            st = self._graphs[key] = self._make_stock_step(key, latents, cond, guidance_scale)
+                self._graphs.pop(next(iter(self._graphs)))     # least recently used (hits are re-inserted at the end)
+            st = self._make_stock_step(key, latents, cond, guidance_scale)
         else:
             st["load_cond"](cond)
+        self._graphs[key] = st
         st["latents"].copy_(latents)
         for i, t in enumerate(sched.timesteps):
             st["t"].fill_(float(t))

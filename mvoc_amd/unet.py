@@ -354,6 +354,7 @@ class ResnetBlock2D(Hookable):
         h = ops.groupnorm(x, *self.norm1, x2=skip, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5,
                           silu=True)
         if eng._tall is not None and self.tslice is not None:
+            assert eng._tall.shape[0] == temb_act.shape[0], "batched time projection of another call"
             tproj = eng._tall[:, self.tslice[0]:self.tslice[0] + self.tslice[1]]  # [B, Cout] columns of the batched projection
         else:
             tproj = self.time_emb_proj(temb_act)  # [B, Cout]; identical for all frames of a sample
@@ -496,6 +497,7 @@ class I2VGenXLUNet:
         inputs, computes its F/world frames (temporal sections pixel-sharded, see that module) and returns the FULL
         output (one all-gather of the 4-channel prediction), so the loops around the UNet stay unchanged."""
         self.shard = shard
+        self.shard_generation = getattr(self, "shard_generation", 0) + 1  # cache keys: id() of a freed shard can be reused
         self._mask_cache = (None, None, None)
         self._section_mask_cache = {}
         return self
@@ -861,8 +863,14 @@ class I2VGenXLUNet:
             yield from blk.attentions
 
     @torch.no_grad()
-    def _forward(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings, encoder_hidden_states,
-                 multi_frame_guidance, conditioning=None):
+    def _forward(self, *args, **kw):
+        try:
+            return self._forward_impl(*args, **kw)
+        finally:
+            self._tall = None  # the batched time projection belongs to this call only (a resnet run on its own recomputes it)
+
+    def _forward_impl(self, sample, timestep, fps, image_latents_first, image_latents, image_embeddings, encoder_hidden_states,
+                      multi_frame_guidance, conditioning=None):
         if not self._loaded:
             raise RuntimeError("I2VGenXLUNet: load_state_dict() or init_random() first")
         cfg = self.config

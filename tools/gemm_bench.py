@@ -13,7 +13,12 @@ from mvoc_amd import ops, _ffi
 from mvoc_amd.unet import I2VGenXLUNet
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-TILES = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+def _tile(x):  # "81" or "81:3" = tile 81 with a forced 3-way split-K (encoded as 1000 * split + tile)
+    t, _, sk = x.partition(":")
+    return int(t) + 1000 * int(sk or 0)
+
+
+TILES = [_tile(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 eng = I2VGenXLUNet(device="cuda:0").init_random(8888)
 F, h, w = 16, 64, 64
 g = torch.Generator().manual_seed(0)
@@ -68,17 +73,19 @@ for key, (d, cnt) in rec.items():
         d.workspace, d.workspace_bytes = wsbuf.data_ptr(), wsbuf.numel() * 4
     best = None
     per = {}
-    for tile in TILES:
+    for tile_code in TILES:
+        tile, sk = tile_code % 1000, tile_code // 1000
         d.tile = tile
+        d.split_k = sk
+        if sk and not (d.m <= 8192 and d.k >= 2048 and d.act != 1 and d.k % (64 * sk) == 0):
+            continue
         if tile == 66 and (d.act == 1 or d.n % 320):
             continue
         if tile == 67 and d.n % 256:
             continue
         if tile in (2, 12, 14, 62, 64) and (d.act == 1 or d.n % 160):
             continue
-        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 61, 63, 65, 67, 91):
-            continue
-        if tile in (91, 92) and (d.m < 16384 or (tile == 92 and d.n % 320) or (tile == 91 and d.n % 256 and d.n < 1024)):
+        if d.act == 1 and tile not in (0, 1, 3, 4, 11, 13, 15, 61, 63, 65, 67, 81, 83):
             continue
         try:
             for _ in range(2):
@@ -94,9 +101,9 @@ for key, (d, cnt) in rec.items():
             us = e0.elapsed_time(e1) / n * 1e3
         except RuntimeError as e:
             continue
-        per[tile] = us
+        per[tile_code] = us
         if best is None or us < best[1]:
-            best = (tile, us)
+            best = (tile_code, us)
     rows.append((key, cnt, fl, per, best))
     tot_fl += fl * cnt
 tt = 0
