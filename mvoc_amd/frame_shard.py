@@ -27,6 +27,9 @@ With the ``gloo`` backend (CPU tests, or two test processes sharing one GPU) the
                 on host copies for the CPU tests and for two test processes sharing one GPU).
   * ``"rccl"``  the library's own communicator behind the C ABI (``mvoc_allgather_frames`` / ``mvoc_alltoall_frames``,
                 ``include/mvoc_hip.h``): torch.distributed only carries the 128-byte unique id.  Device tensors only.
+                EXPERIMENTAL: exercised at world size 1 only (the build and test boxes have one GPU) -- per-peer byte
+                counts, peer order and the all-to-all signature are unverified across ranks; the default transport is
+                ``"torch"``.  Use as a context manager (or call ``close()``) to destroy the communicator.
 The pack / unpack copies either side of an exchange are one HIP kernel (``mvoc_permute_rows_f16``) for device tensors and
 plain torch for host tensors, so the module stays importable and testable on a CPU-only machine.
 """
@@ -37,7 +40,7 @@ __all__ = ["FrameShard"]
 
 
 class FrameShard:
-    def __init__(self, group=None, exchange="a2a", transport="torch"):
+    def __init__(self, group=None, exchange="a2a", transport="torch", device=None):
         if not dist.is_initialized():
             raise RuntimeError("FrameShard: torch.distributed is not initialised (launch one process per GPU)")
         if exchange not in ("a2a", "allgather"):
@@ -52,6 +55,7 @@ class FrameShard:
         self.bytes_sent = 0  # per-rank payload handed to the collectives since the last reset (accounting only)
         self.transport = transport
         self._comm = None
+        self.device = device  # transport "rccl": the GPU the communicator is created on (default: the current device)
         if transport == "rccl":
             self._native_init()
 
@@ -65,7 +69,10 @@ class FrameShard:
         box = [bytes(buf)]
         dist.broadcast_object_list(box, src=0, group=self.group)  # the only use of torch.distributed on this transport
         comm = C.c_void_p()
-        check(lib.mvoc_comm_init(box[0], self.rank, self.world, C.byref(comm)), "comm_init")
+        # ncclCommInitRank binds the communicator to the CURRENT HIP device: make that the engine's device, not whatever the
+        # caller's thread happens to have selected
+        with torch.cuda.device(self.device if self.device is not None else torch.cuda.current_device()):
+            check(lib.mvoc_comm_init(box[0], self.rank, self.world, C.byref(comm)), "comm_init")
         self._comm = comm
 
     def close(self):
@@ -73,6 +80,18 @@ class FrameShard:
             from ._ffi import check, lib
             check(lib.mvoc_comm_destroy(self._comm), "comm_destroy")
             self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may already be gone)
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def _native(self, t):
         if self._comm is None:

@@ -125,3 +125,5 @@ def test_native_rccl_transport_world1(tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     rep = json.load(open(tmp_path / "rccl_r0.json"))
     assert rep["exchanges_ok"] and rep["forward_max_abs"] == 0.0, rep
+    # a sharded iteration on the native transport captured into a hipGraph replays to the eager result
+    assert rep["graph_error"] is None and rep["graph_replay_max_abs"] == 0.0, rep

@@ -68,9 +68,9 @@ def _metrics(out, ref):
     return float((out - ref).norm() / ref.norm()), float((out - ref).abs().max() / ref.abs().max())
 
 
-def _inputs(g, b, f):
+def _inputs(g, b, f, h=H, w=W):
     r = lambda *s: torch.randn(*s, generator=g).half().float()
-    return dict(sample=r(b, 4, f, H, W), il1=0.5 * r(b, 4, f, H, W), il=0.5 * r(b, 4, f, H, W), ie=r(b, f, 1024), eh=r(b, 77, 1024),
+    return dict(sample=r(b, 4, f, h, w), il1=0.5 * r(b, 4, f, h, w), il=0.5 * r(b, 4, f, h, w), ie=r(b, f, 1024), eh=r(b, 77, 1024),
                 fps=torch.tensor([8] * b))
 
 
@@ -94,6 +94,21 @@ def test_stock_forward_full_width(pair):
     out = eng(x["sample"], 501, x["fps"], image_latents=x["il"], image_embeddings=x["ie"][:, :1], encoder_hidden_states=x["eh"])[0]
     rel, mx = _metrics(out, ref)
     print(f"full-width stock forward B=1 F=16 {H}x{W}: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}")
+    assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD, (rel, mx)
+
+
+def test_stock_forward_full_width_odd_size(pair):
+    """the reference's own demo size is 1280x720 -> 90x160 latents: an odd pyramid 90 -> 45 -> 23 -> 12 with forced-size
+    upsampling (pipeline_i2vgen_xl.py:156-164, 328-329), T = 14 400 tokens (ragged flash tiles), image borders inside GEMM
+    tiles.  Same structure at a size the oracle finishes in seconds: 23 x 40 -> 12 x 20 -> 6 x 10 -> 3 x 5 (920 tokens, not a
+    multiple of the 128-query / 64-key attention tiles; 23 and 5 odd: both upsamplers towards them take the forced-size path)."""
+    o, eng = pair
+    g = torch.Generator().manual_seed(23)
+    x = _inputs(g, 1, 4, 23, 40)
+    ref = o(x["sample"], 381, x["fps"], x["il"], x["ie"][:, :1], x["eh"])[0]
+    out = eng(x["sample"], 381, x["fps"], image_latents=x["il"], image_embeddings=x["ie"][:, :1], encoder_hidden_states=x["eh"])[0]
+    rel, mx = _metrics(out, ref)
+    print(f"full-width stock forward B=1 F=4 23x40: rel-L2 {rel:.2e}, max-abs/max {mx:.2e}")
     assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD, (rel, mx)
 
 
@@ -196,7 +211,7 @@ def test_one_inversion_and_one_composition_step_full_width(pair, trio):
         ref = loops_ref.scheduler_step_5d(rs, loops_ref.cfg_combine(rn[3:4], rn[4:5], 9.0), 981, lat)
         rel, _ = _metrics(cst["latents"], ref)
         print(f"full-width composition step t=981: latents rel-L2 {rel:.2e}")
-        assert rel <= 3e-3, rel  # CFG 9.0 amplifies the (cond - uncond) difference of two fp16 predictions
+        assert rel <= REL_L2_STEP, rel  # (measured 1.5e-4: at t = 981 the update is dominated by the latent itself)
 
 
 def test_cfg1_8frame_256sq_10step_inversion(pair, tmp_path):

@@ -115,14 +115,14 @@ def test_pipeline_returns_frames_with_a_vae():
 
 
 # ---- the kernels the VAE adds ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 11, 13, 91])
+@pytest.mark.parametrize("tile", [0, 11, 13, 81, 82])
 def test_conv3x3_bottom_right_padding_exact(tile):
     """Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + conv2d(stride=2, padding=0) == the gather's pad_mode=1, bit-exact on
     integer data (any shifted tap or a wrong border shows as a wrong integer)"""
     from mvoc_amd import ops
     from mvoc_amd.unet import pack_conv3x3
     g = torch.Generator().manual_seed(tile)
-    n, c, cout, h, w = (4, 128, 128, 16, 16) if tile != 91 else (16, 128, 256, 64, 64)
+    n, c, cout, h, w = (4, 128, 128, 16, 16) if tile < 80 else (16, 128, 256, 64, 64)
     x = torch.randint(-1, 2, (n, c, h, w), generator=g).float()
     wt = torch.randint(-1, 2, (cout, c, 3, 3), generator=g).float()
     b = torch.randint(-4, 5, (cout,), generator=g).float()
