@@ -891,14 +891,14 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   if (tile == 0 && g8_ok && d->m >= 4096 && d->k >= 512 && !(d->n <= 640 && d->k <= 640)) {
     // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
     // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last
-    // tile of a row and CUs idle in the last wave of blocks (one block per CU).  The 320-wide form runs ~7 % below the 256-wide
-    // one per flop (its register file is full: accumulator copies in the loop).
+    // tile of a row and CUs idle in the last wave of blocks (one block per CU).  The 320-wide form runs within ~3 % of the 256-wide
+    // one per flop.
     auto eff = [&](int bx, double rate) {
       const int64_t nt = (d->n + bx - 1) / bx, blocks = ((d->m + 255) / 256) * nt;
       return (double)d->n / (double)(nt * bx) * (double)blocks / (double)(((blocks + 255) / 256) * 256) * rate;
     };
     const double e81 = eff(256, 1.0);
-    const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.93) : 0.0;
+    const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.97) : 0.0;
     if (e81 >= 0.55 || e82 >= 0.55) {
       tile = e82 > e81 ? 82 : 81;
     } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
@@ -964,9 +964,9 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
-    const bool t8 = tile == 81 || tile == 82 || tile == 83;
+    const bool t8 = tile == 81 || tile == 82;
     const int bm = t8 || tile == 14 || tile == 64 || tile == 66 || tile == 67 || tile % 10 == 5 ? 256 : 128;
-    const int bn = tile == 66 || tile == 82 ? 320 : (tile == 67 || tile == 81 || tile == 83) ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
+    const int bn = tile == 66 || tile == 82 ? 320 : (tile == 67 || tile == 81) ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (model_sk > 0) {
@@ -981,7 +981,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     }
   }
   {
-    if (tile == 81 || tile == 82 || tile == 83) {  // 83: the 256-wide tile without retained Y0 fragments (tuning)
+    if (tile == 81 || tile == 82) {
       MVOC_REQUIRE(g8_ok && !(tile == 82 && d->act == MVOC_ACT_GEGLU), -2,
                    "gemm: tiles 81 / 82 need k, cin, c1 %% 64 == 0, 16-byte addressable outputs, row statistics, operands < 2 GB "
                    "(82: no GEGLU)");
@@ -995,7 +995,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
           a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
         }
       }
-      const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : tile == 83 ? 2560 : 320, s);
+      const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : 320, s);
       if (rc == 0 && a.split_k > 1) {
         const long nthr = (long)a.M * (a.N / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);

@@ -244,12 +244,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     dst[j][0] = G8_LDP(yr0, (off) + j * 2048);                  \
     dst[j][1] = G8_LDP(yr1, (off) + j * 2048);                  \
   }
+  // XT = 5: the accumulate is pinned IN PLACE by an asm statement (D = C): the register file is full (160 accumulators + 56
+  // fragment registers) and hipcc's out-of-place MFMA form cost ~110 v_mov_b64 accumulator copies per two K tiles.  Hazards
+  // hipcc no longer sees: an MFMA's D feeding the next MFMA as C needs no wait state; every other reader of an accumulator
+  // (the epilogue) sits behind the loop's last s_barrier; the A / B operands come from LDS reads that hipcc waits for (they are
+  // register inputs of the statement).
+  auto mma = [&](f32x4& c, const half8_t& a, const half8_t& b) {
+    if constexpr (XT == 5) {
+      asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+  };
 #define G8_MMA(A, B, YF)                                                                                              \
   do {                                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < XT; ++i)                     \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-            acc[A][B][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[i][s], YF[j][s], acc[A][B][i][j], 0, 0, 0);  \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) mma(acc[A][B][i][j], xf[i][s], YF[j][s]);                       \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
   } while (0)
 
@@ -507,11 +518,10 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
 // only with bx = 256, every operand spanning < 2 GB (32-bit MUBUF offsets).
 int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
   if (a.upsample) {  // (rare: the three upsampler convs of a forward) one form serves every width
-    if (bx == 256 || bx == 2560 || bx == 320) return launch8<4, true, true, true, false>(a, s);
+    if (bx == 256 || bx == 320) return launch8<4, true, true, true, false>(a, s);
   } else {
     const bool affine = a.a_mode != MVOC_A_CONV3X3 || (a.stride == 1 && a.pad == 1 && a.hsrc == a.hout && a.wsrc == a.wout);
     if (bx == 256 || (bx == 320 && !affine)) return launch8<4, true, true, false, false>(a, s);
-    if (bx == 2560) return launch8<4, false, true, false, false>(a, s);
     if (bx == 320) return launch8<5, false, false, false, true>(a, s);
   }
   mvoc_set_error("gemm8: unsupported tile width %d", bx);

@@ -35,7 +35,7 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82, 83])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
@@ -164,7 +164,7 @@ def _from_rows(r, n, h, w):
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82, 83])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 8, 8, 1), (32, 96, 7, 9, 1), (64, 128, 9, 6, 2), (8, 64, 8, 8, 1)])
 def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     if tile and cin % 64:
@@ -182,7 +182,7 @@ def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82, 83])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
 def test_conv3x3_concat_glds(ops, tile):
     """two-source gather (decoder skip concat) with both channel counts multiples of 64"""
     from mvoc_amd.unet import pack_conv3x3
@@ -213,7 +213,7 @@ def test_conv3x3_concat_temb_resid(ops):
     assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 13, 81, 82, 83])
+@pytest.mark.parametrize("tile", [0, 13, 81, 82])
 @pytest.mark.parametrize("size", [None, (11, 7)])
 def test_conv3x3_upsample(ops, size, tile):
     from mvoc_amd.unet import pack_conv3x3
@@ -230,7 +230,7 @@ def test_conv3x3_upsample(ops, size, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82, 83])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
 @pytest.mark.parametrize("frames", [1, 3, 16])
 def test_tconv3(ops, frames, tile):
     from mvoc_amd.unet import pack_tconv
@@ -252,7 +252,7 @@ def test_tconv3(ops, frames, tile):
 # time-embedding row add and the residual.  Operands are small integers: every product and every fp32 partial sum is
 # exact and |result| < 2048 is exact in fp16, so the comparison with torch's CPU conv is BIT-EXACT -- any indexing slip in
 # a tile (tap order, source switch, swizzle, tail rows) shows as a wrong integer.
-PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82, 83]
+PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82]
 _prod_cache = {}
 
 
@@ -297,7 +297,7 @@ def test_conv3x3_production_tiles_exact(ops, case, tile):
     assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
 
 
-@pytest.mark.parametrize("tile", [81, 82, 83])
+@pytest.mark.parametrize("tile", [81, 82])
 @pytest.mark.parametrize("split_k", [2, 4])
 def test_g8_split_k_exact(ops, split_k, tile):
     """eight-phase kernel with K slices (fp32 slabs + the reduce pass)"""
@@ -357,7 +357,7 @@ def test_linear_production_tiles_exact(ops, m, n, k, tile):
     assert torch.equal(out.float().cpu(), ref), f"tile {tile}"
 
 
-@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67, 81, 83])
+@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67, 81])
 @pytest.mark.parametrize("m,c,inner", [(16384, 320, 1280), (4096, 1280, 5120)])
 def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
     """GEGLU feed-forward entry with the LayerNorm folded in, at C = 320 (L0) and C = 1280 (L2) and production rows, on the
@@ -883,7 +883,7 @@ def test_pnp_cfg_off_layout_bit_exact(ops, nobj, bg):
     assert torch.equal(bits(dx), bits(ref))
 
 
-@pytest.mark.parametrize("tile", [81, 82, 83])
+@pytest.mark.parametrize("tile", [81, 82])
 @pytest.mark.parametrize("shape", [(3, 64, 320, 9, 7), (2, 128, 320, 16, 16), (5, 64, 640, 5, 33), (1, 64, 160, 3, 3), (2, 192, 320, 40, 8)])
 def test_conv3x3_g8_borders(ops, tile, shape):
     """eight-phase kernel: image / row borders come from the hardware range check of the LDS-DMA (rows outside the image carry
@@ -918,7 +918,7 @@ def test_conv3x3_g8_two_sources(ops):
     wt = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / 40).half()
     b = torch.randn(cout, generator=g).half()
     ref = F.conv2d(torch.cat([x1, x2], 1).float(), wt.float(), b.float(), padding=1)
-    for tile in (0, 81, 82, 83):
+    for tile in (0, 81, 82):
         out, _, _ = ops.conv3x3(dev(_nhwc(x1)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=h, wd=w, x2=dev(_nhwc(x2)), n_store=cout,
                                 tile=tile)
         assert rel_l2(_from_rows(out, n, h, w), ref) < 1.5e-3

@@ -265,7 +265,6 @@ int main(int argc, char** argv) {
       {"base t66 320x256", run_base<66>},
       {"base auto", run_base<0>},
       {"lib t81 g8 256", run_base<81>},
-      {"lib t83 g8 256 noretain", run_base<83>},
       {"lib t82 g8 320", run_base<82>},
       {"lab g8 16x16", run_g8<0, true, true>},
   };
