@@ -188,28 +188,13 @@ def rccl_native(out_dir):
     ref = eng.forward_ext(*inp)[0]
     eng.set_frame_shard(sh)
     got = eng.forward_ext(*inp)[0]
-    # the native transport's exchanges are plain stream-ordered C-ABI launches: a sharded iteration must be capturable into a
-    # hipGraph (RCCL supports stream capture) and the replay must reproduce the eager result bit for bit
-    graph_max, graph_err = None, None
-    try:
-        from mvoc_amd.pipeline import GraphedStep
-        box = {}
-
-        def body():
-            box["out"] = eng.forward_ext(*inp)[0]
-
-        step = GraphedStep(body, warmup=1)
-        box["out"].zero_()
-        step()
-        torch.cuda.synchronize()
-        graph_max = float((box["out"].float() - got.float()).abs().max())
-    except Exception as e:  # noqa: BLE001
-        graph_err = f"{type(e).__name__}: {e}"
     eng.set_frame_shard(None)
     torch.cuda.synchronize()
     sh.close()
-    json.dump({"rank": rank, "exchanges_ok": ok, "forward_max_abs": float((got.float() - ref.float()).abs().max()),
-               "graph_replay_max_abs": graph_max, "graph_error": graph_err},
+    # (Capturing a sharded iteration on this transport into a hipGraph was tried in round 3: the capture of the RCCL calls
+    # never returns at world size 1 with the RCCL copy torch ships -- the worker had to be killed by the test's timeout -- so
+    # sharded iterations stay eager)
+    json.dump({"rank": rank, "exchanges_ok": ok, "forward_max_abs": float((got.float() - ref.float()).abs().max())},
               open(os.path.join(out_dir, f"rccl_r{rank}.json"), "w"))
 
 

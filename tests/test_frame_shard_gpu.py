@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(nproc, port, *args, timeout=900):
+def launch(nproc, port, *args, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "tests", "shard_worker.py"), *args]
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
@@ -125,5 +125,3 @@ def test_native_rccl_transport_world1(tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     rep = json.load(open(tmp_path / "rccl_r0.json"))
     assert rep["exchanges_ok"] and rep["forward_max_abs"] == 0.0, rep
-    # a sharded iteration on the native transport captured into a hipGraph replays to the eager result
-    assert rep["graph_error"] is None and rep["graph_replay_max_abs"] == 0.0, rep

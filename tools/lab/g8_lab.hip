@@ -29,6 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     __builtin_amdgcn_s_barrier();            \
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
+#define LBAR()                               \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    if (!(ABL & 1)) __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
 
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   const unsigned q = nblk >> 3, r = nblk & 7u, x = bid & 7u, i = bid >> 3;
@@ -38,7 +44,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 constexpr int HT = 16384;  // bytes per half-tile slot: 128 rows x 128 B
 
 // SHAPE 0: v_mfma_f32_16x16x32_f16, 1: v_mfma_f32_32x32x16_f16
-template <int SHAPE, bool STAG, bool PRIO>
+template <int SHAPE, bool STAG, bool PRIO, int ABL = 0>  // ABL (timing only, wrong results): 1 = no barriers in the loop, 2 = no LDS-DMA in the loop, 4 = no fragment reads in the loop
 __global__ __launch_bounds__(512) void g8_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Y,
                                                  half_t* __restrict__ out, int NX, int NY, int K, int ldo, int nxt) {
   __shared__ __attribute__((aligned(1024))) char smem[8 * HT];
@@ -139,41 +145,42 @@ __global__ __launch_bounds__(512) void g8_kernel(const half_t* __restrict__ X, c
   do {                                                                                                    \
     const int hb_ = 4 * (t) + 6;                                                                          \
     /* phase 1: (X0, Y0) */                                                                               \
-    RDY(yf0, 4 * (P) + 0);                                                                                \
+    if (!(ABL & 4)) { RDY(yf0, 4 * (P) + 0); }                                                                                \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    RDX(4 * (P) + 1);                                                                                     \
+    if (!(ABL & 4)) { RDX(4 * (P) + 1); }                                                                                     \
     asm volatile("" ::: "memory");                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if (hb_ + 1 < nh) ISSUE(3, (4 * (P) + 7) & 7);                                                        \
+    if (!(ABL & 2) && hb_ + 1 < nh) ISSUE(3, (4 * (P) + 7) & 7);                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XT * NS) : "memory");                                      \
-    BAR();                                                                                                \
+    if (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(XT * NS) : "memory");                                      \
+    LBAR();                                                                                                \
     MMA(0, 0, yf0);                                                                                       \
-    BAR();                                                                                                \
+    LBAR();                                                                                                \
     /* phase 2: (X0, Y1) */                                                                               \
-    RDY(yf1, 4 * (P) + 2);                                                                                \
+    if (!(ABL & 4)) { RDY(yf1, 4 * (P) + 2); }                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if (hb_ + 2 < nh) ISSUE(0, (4 * (P) + 8) & 7);                                                        \
-    BAR();                                                                                                \
+    if (!(ABL & 2) && hb_ + 2 < nh) ISSUE(0, (4 * (P) + 8) & 7);                                                        \
+    LBAR();                                                                                                \
     MMA(0, 1, yf1);                                                                                       \
-    BAR();                                                                                                \
+    LBAR();                                                                                                \
     /* phase 3: (X1, Y1) */                                                                               \
-    RDX(4 * (P) + 3);                                                                                     \
+    if (!(ABL & 4)) { RDX(4 * (P) + 3); }                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if (hb_ + 3 < nh) ISSUE(1, (4 * (P) + 9) & 7);                                                        \
-    BAR();                                                                                                \
+    if (!(ABL & 2) && hb_ + 3 < nh) ISSUE(1, (4 * (P) + 9) & 7);                                                        \
+    LBAR();                                                                                                \
     MMA(1, 1, yf1);                                                                                       \
-    BAR();                                                                                                \
+    LBAR();                                                                                                \
     /* phase 4: (X1, Y0) */                                                                               \
-    if (hb_ + 4 < nh) ISSUE(2, (4 * (P) + 10) & 7);                                                       \
+    if (!(ABL & 2) && hb_ + 4 < nh) ISSUE(2, (4 * (P) + 10) & 7);                                                       \
     if ((t) + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                    \
     else if ((t) + 2 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
-    BAR();                                                                                                \
+    LBAR();                                                                                                \
     MMA(1, 0, yf0);                                                                                       \
-    BAR();                                                                                                \
+    LBAR();                                                                                                \
   } while (0)
 
+  if (ABL & 4) { RDY(yf0, 0); RDX(1); RDY(yf1, 2); }
   int t = 0;
 #pragma unroll 1
   for (; t + 1 < nk; t += 2) {
@@ -237,11 +244,11 @@ struct Variant {
 
 template <int TILE>
 void run_base(const half_t* X, const half_t* Y, half_t* out, int NX, int NY, int K, hipStream_t s);
-template <int SHAPE, bool STAG, bool PRIO>
+template <int SHAPE, bool STAG, bool PRIO, int ABL = 0>
 void run_g8(const half_t* X, const half_t* Y, half_t* out, int NX, int NY, int K, hipStream_t s) {
   if (NX % 256) { run_base<67>(X, Y, out, NX, NY, K, s); return; }
   const int nxt = NX / 256, nyt = NY / 256;
-  hipLaunchKernelGGL((g8_kernel<SHAPE, STAG, PRIO>), dim3(nxt * nyt), dim3(512), 0, s, X, Y, out, NX, NY, K, NX, nxt);
+  hipLaunchKernelGGL((g8_kernel<SHAPE, STAG, PRIO, ABL>), dim3(nxt * nyt), dim3(512), 0, s, X, Y, out, NX, NY, K, NX, nxt);
 }
 template <int TILE>
 void run_base(const half_t* X, const half_t* Y, half_t* out, int NX, int NY, int K, hipStream_t s) {
@@ -267,6 +274,11 @@ int main(int argc, char** argv) {
       {"lib t81 g8 256", run_base<81>},
       {"lib t82 g8 320", run_base<82>},
       {"lab g8 16x16", run_g8<0, true, true>},
+      {"lab g8 ABL no barriers", run_g8<0, true, true, 1>},
+      {"lab g8 ABL no DMA", run_g8<0, true, true, 2>},
+      {"lab g8 ABL no reads", run_g8<0, true, true, 4>},
+      {"lab g8 ABL no DMA no reads", run_g8<0, true, true, 6>},
+      {"lab g8 ABL MFMA only", run_g8<0, true, true, 7>},
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
