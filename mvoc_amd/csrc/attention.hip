@@ -16,6 +16,8 @@
 // tattn_kernel  -- temporal self-attention: one wave per (sample, pixel, head); the sequence is the frame axis
 //   (<= 32 frames), rows are strided by H*W*C in the canonical layout so no [B*HW, F, C] copy is ever made.
 //   Same transposed-score scheme with a single 32x32 tile; V^T goes through a 4 KB wave-private LDS image.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {

@@ -401,6 +401,52 @@ def test_flash_attn(ops, tq, tk, heads, kv_bdiv):
     assert (out.float().cpu() - ref).abs().max() < 1e-2
 
 
+@pytest.mark.parametrize("tq,tk,heads,kv_bdiv,nb", [(1024, 1024, 5, 1, 3), (300, 512, 2, 2, 4), (256, 256, 1, 1, 2), (4096, 4096, 1, 1, 1),
+                                                     (920, 960, 2, 1, 2), (2100, 192, 1, 1, 1)])
+def test_flash_attn_eight_wave(ops, tq, tk, heads, kv_bdiv, nb):
+    """many KV tiles (3 / 4 / 8 / 15 / 16 / 64), query counts that leave waves of the last block without rows, shared K/V across
+    batch entries, strided q/k/v views of a fused QKV buffer (written for the eight-wave laboratory kernel of round 3,
+    tools/lab/flash2_kernel.hip.inc; kept as coverage of the production kernel at the network's real token counts)"""
+    g = torch.Generator().manual_seed(tq + tk + heads)
+    c = heads * 64
+    qkv = torch.randn(nb * tq, 3 * c, generator=g).half()
+    kv = torch.randn((nb // kv_bdiv) * tk, 2 * c, generator=g).half()
+    dq, dkv = dev(qkv), dev(kv)
+    out = ops.flash_attn(dq[:, c:2 * c], dkv[:, :c], dkv[:, c:], nbatch=nb, heads=heads, tq=tq, tk=tk, kv_bdiv=kv_bdiv)
+    q4 = qkv[:, c:2 * c].float().reshape(nb, tq, heads, 64).transpose(1, 2)
+    k4 = kv[:, :c].float().reshape(nb // kv_bdiv, tk, heads, 64).transpose(1, 2).repeat_interleave(kv_bdiv, 0)
+    v4 = kv[:, c:].float().reshape(nb // kv_bdiv, tk, heads, 64).transpose(1, 2).repeat_interleave(kv_bdiv, 0)
+    ref = F.scaled_dot_product_attention(q4, k4, v4).transpose(1, 2).reshape(nb * tq, c)
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+
+
+def test_flash_attn_eight_wave_large_scores(ops):
+    """spiked keys in different KV tiles force running-max jumps (the online-softmax rescale branch); an exact-integer value
+    matrix makes a wrong V fragment map (transposed LDS read) show as a wrong integer"""
+    g = torch.Generator().manual_seed(5)
+    t = 512
+    q = torch.randn(t, 64, generator=g).half()
+    k = torch.randn(t, 64, generator=g).half()
+    v = torch.randn(t, 64, generator=g).half()
+    k[70] = q[5] * 4
+    k[200] = q[5] * 8
+    k[300] = q[9] * 10
+    k[450] = q[300] * 9
+    out = ops.flash_attn(dev(q), dev(k), dev(v), nbatch=1, heads=1, tq=t, tk=t)
+    ref = F.scaled_dot_product_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None])[0, 0]
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+    # one-hot attention: key j matches query j overwhelmingly -> out[j] == v[j] exactly (integers), for every (key, d) position
+    eye = torch.zeros(t, 64)
+    code = torch.arange(t)
+    for bit in range(9):
+        eye[:, bit] = ((code >> bit) & 1).float() * 2 - 1
+    qe = (eye * 24).half()
+    vi = torch.randint(-64, 65, (t, 64), generator=g).half()
+    out = ops.flash_attn(dev(qe), dev(qe), dev(vi), nbatch=1, heads=1, tq=t, tk=t)
+    assert torch.equal(out.float().cpu(), vi.float())
+
+
 def test_flash_attn_large_scores(ops):
     """spiked keys force big running-max jumps between KV tiles (online-softmax rescale path)"""
     g = torch.Generator().manual_seed(3)
