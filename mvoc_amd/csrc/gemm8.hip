@@ -29,6 +29,12 @@
 
 namespace {
 
+// epilogue stores non-temporal: a block's 128 KB output tile leaves in a chip-wide burst while its CU idles (s_endpgm waits for the
+// stores), and nobody re-reads it from this XCD's L2 (the consumer is another kernel, the tensor several times the L2): +7 % at
+// K = 640, +2 % at K = 1280, +1 % on the job (profiles/r3/nt_store_ab.txt)
+#ifndef G8_NT_STORE
+#define G8_NT_STORE 1
+#endif
 constexpr unsigned G8_OOB = 0x80000000u;  // >= num_records of every resource: the load returns zeros
 
 #define G8_BAR()                         \
@@ -489,7 +495,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
         }
-        *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+        if (G8_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n));
+        else *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
