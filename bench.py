@@ -292,7 +292,7 @@ def roofline_leg(job, steps):
             break
         traffic_note = f"{rel} was taken with another build of the library: not reported"
     return {
-        "bound": "mfma", "kernel": "implicit-GEMM family: gemm_glds_kernel / gemm_kernel (linear / conv3x3 / temporal conv) + xslin_kernel (K = 320 projections)",
+        "bound": "mfma", "kernel": "implicit-GEMM family: gemm8_kernel (eight-phase 256-pixel tiles: 69 % of the family's time) + gemm_glds_kernel / gemm_kernel (the general tiles) for linear / conv3x3 / temporal conv, + xslin_kernel (K = 320 projections)",
         "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 --pmc passes over the same step mix)",
         "traffic_source": traffic_src, "traffic_note": traffic_note,

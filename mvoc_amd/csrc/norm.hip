@@ -305,26 +305,38 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict
   if (row >= rows) return;
   const int nch = c / 8;
   const half_t* xr = x + row * c;
-  const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+  // two passes (mean, then squared deviations) like F.layer_norm; rows of up to 2048 channels stay in registers (c <= 2048 is
+  // checked by the host), wider ones are re-read from L2
+  half8_t v[4];
   float s1 = 0.f, s2 = 0.f;
-  for (int cc = lane; cc < nch; cc += 64) {
-    const half8_t v = *reinterpret_cast<const half8_t*>(xr + cc * 8);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const half2_t v2 = {v[2 * e], v[2 * e + 1]};
-      s1 = __builtin_amdgcn_fdot2(v2, one2, s1, false);
-      s2 = __builtin_amdgcn_fdot2(v2, v2, s2, false);
+  for (int i = 0; i < 4; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < nch) {
+      v[i] = *reinterpret_cast<const half8_t*>(xr + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1 += (float)v[i][e];
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o);
-    s2 += __shfl_xor(s2, o);
+  for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+  const float mean = s1 / c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dv = (float)v[i][e] - mean;
+        s2 += dv * dv;
+      }
+    }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
   if (lane == 0) {
-    const float mu = s1 / c;
-    stats[2 * row] = mu;
-    stats[2 * row + 1] = rsqrtf(fmaxf(s2 / c - mu * mu, 0.f) + eps);
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rsqrtf(s2 / c + eps);
   }
 }
 
@@ -374,7 +386,7 @@ extern "C" int mvoc_softmax_rows_f16(void* x, int64_t rows, int32_t cols, void* 
 }
 
 extern "C" int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream) {
-  MVOC_REQUIRE(x && stats && rows > 0 && c >= 8 && c % 8 == 0, -1, "row_stats: bad args");
+  MVOC_REQUIRE(x && stats && rows > 0 && c >= 8 && c % 8 == 0 && c <= 2048, -1, "row_stats: bad args (c %% 8 == 0, c <= 2048)");
   hipStream_t s = (hipStream_t)stream;
   MvocProfScope prof(MVOC_FAM_LN, s, 2.0 * (double)rows * c);
   const long nblk = (rows + 3) / 4;

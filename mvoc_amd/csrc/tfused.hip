@@ -118,13 +118,21 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
       for (int e = 0; e < 4; ++e) {
         const half2_t v2 = {xf[s][2 * e], xf[s][2 * e + 1]};
         s1 = __builtin_amdgcn_fdot2(v2, one2, s1, false);
-        s2 = __builtin_amdgcn_fdot2(v2, v2, s2, false);
       }
   }
   s1 += __shfl_xor(s1, 32);
-  s2 += __shfl_xor(s2, 32);
   const float mu = s1 / (float)C;
-  const float rs = rsqrtf(fmaxf(s2 / (float)C - mu * mu, 0.f) + p.eps);
+  // second pass over the register-resident row: sum of squared deviations (as F.layer_norm; E[x^2] - mu^2 cancels for rows
+  // whose mean is large against their spread)
+#pragma unroll
+  for (int s = 0; s < NK; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dv = (float)xf[s][e] - mu;
+      s2 = __builtin_fmaf(dv, dv, s2);
+    }
+  s2 += __shfl_xor(s2, 32);
+  const float rs = rsqrtf(s2 / (float)C + p.eps);
   // normalise the row in place, once: x^ = (x - mean) * rstd in fp16.  gamma rides on the weights (W' = W * gamma) and beta in the
   // per-channel constant c = beta @ W^T, so a projection tile's fix-up is ONE add per value -- no row-sum correction, no
   // per-row statistics in the epilogues (the earlier rstd * (acc - mean * rowsum) + c form cost ~1000 cycles per stage beside

@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
     const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
+      // two passes over the register-resident row (mean, then sum of squared deviations), like F.layer_norm: the one-pass
+      // E[x^2] - mu^2 form loses the variance of rows whose mean is large against their spread (outlier channels)
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int s = 0; s < NK; ++s)
@@ -165,12 +167,18 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
         for (int e = 0; e < 4; ++e) {
           const half2_t v2 = {xf[g][s][2 * e], xf[g][s][2 * e + 1]};
           s1 = __builtin_amdgcn_fdot2(v2, one2, s1, false);
-          s2 = __builtin_amdgcn_fdot2(v2, v2, s2, false);
         }
       s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
       const float mu = s1 / (float)K;
-      const float rs = rsqrtf(fmaxf(s2 / (float)K - mu * mu, 0.f) + p.eps);
+#pragma unroll
+      for (int s = 0; s < NK; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dv = (float)xf[g][s][e] - mu;
+          s2 = __builtin_fmaf(dv, dv, s2);
+        }
+      s2 += __shfl_xor(s2, 32);
+      const float rs = rsqrtf(s2 / (float)K + p.eps);
 #pragma unroll
       for (int s = 0; s < NK; ++s)
 #pragma unroll

@@ -656,6 +656,39 @@ def test_xs_linear_two_row_groups(ops, n, mode):
     assert (got - ref).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
 
 
+def test_layernorm_fold_rows_with_large_offset(ops):
+    """rows whose mean is large against their spread (outlier channels of a real checkpoint): the folded LayerNorm of the
+    x-stationary linear, of the fused temporal kernel and of mvoc_row_stats_f16 takes its variance in two passes like
+    F.layer_norm -- the one-pass E[x^2] - mu^2 form lost it to cancellation (round-2 advisor finding)"""
+    from mvoc_amd.unet import Linear, pack_tfused_weights
+    g = torch.Generator().manual_seed(77)
+    m, k, n = 4096, 320, 960
+    x = (40.0 + 0.5 * torch.randn(m, k, generator=g)).half()
+    x[::7] = (-25.0 + 0.25 * torch.randn(x[::7].shape, generator=g)).half()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).half()
+    gm, bt = (1 + 0.3 * torch.randn(k, generator=g)).half(), (0.3 * torch.randn(k, generator=g)).half()
+    ln = F.layer_norm(x.float(), (k,), gm.float(), bt.float(), 1e-5)
+    ref = ln.half().float() @ w.float().t()
+    lin = Linear(dev(w)).fold_layernorm(dev(gm), dev(bt))
+    out = lin.call_ln(dev(x), (dev(gm), dev(bt)))          # K = 320: mvoc_xs_linear_f16 with normalize
+    assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)
+    st = ops.row_stats(dev(x), 1e-5).float().cpu()          # {mean, rstd} per row
+    mu, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    assert (st[:, 0] - mu).abs().max() < 1e-3
+    assert ((st[:, 1] - torch.rsqrt(var + 1e-5)) / torch.rsqrt(var + 1e-5)).abs().max() < 1e-4
+    # fused temporal kernel on the same rows (16 frames x 256 pixels)
+    wp = pack_tfused_weights(lin.w_ln, 5)
+    o2 = ops.temporal_qkv_attn(dev(x), wp, lin.ln, nsample=1, frames=16, hw=256, heads=5)
+    qkv = ref.half().float()
+
+    def seq(t):
+        return t.reshape(1, 16, 256, 5, 64).permute(0, 2, 3, 1, 4).reshape(256, 5, 16, 64)
+
+    r2 = F.scaled_dot_product_attention(seq(qkv[:, :320]), seq(qkv[:, 320:640]), seq(qkv[:, 640:]))
+    r2 = r2.reshape(1, 256, 5, 16, 64).permute(0, 3, 1, 2, 4).reshape(m, 320)
+    assert rel_l2(o2, r2) < 4e-3, rel_l2(o2, r2)
+
+
 def test_xs_linear_refuses(ops):
     from mvoc_amd.unet import pack_xs_weights
     x = torch.zeros(64, 96, dtype=torch.float16, device="cuda")

@@ -37,7 +37,7 @@ try:
     digest = open("mvoc_amd/libmvoc_hip.so.stamp").read().strip()
 except OSError:
     digest = None
-j = {"kernel": "implicit-GEMM family (gemm_glds_kernel / gemm_kernel / gemm_pp_kernel / xslin_kernel instantiations + splitk_reduce_kernel)",
+j = {"kernel": "implicit-GEMM family (gemm8_kernel / gemm_glds_kernel / gemm_kernel / xslin_kernel instantiations + splitk_reduce_kernel)",
      "steps": steps, "mix": "3 inversion : 1 composition", "launches": n, "launches_per_step": n / steps,
      "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n, "hbm_bytes_per_launch": (fetch + write) / n,
      "lib_digest": digest,
