@@ -14,7 +14,7 @@ LAB = os.environ.get("MVOC_BUILD_LAB") == "1"  # diagnostic library (in-kernel s
 if LAB:
     LIB = os.path.join(HERE, "libmvoc_hip_lab.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=on"]
+         "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage"]  # the remarks are kept per object (<obj>.res.txt): tests check them
 # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified register file).  In AGPR form hipcc time-shares
 # 32 AGPRs between the S^T and O^T accumulators and emits ~220 v_accvgpr_read/write per K/V tile; VGPR form has none
 # and needs 162 instead of 196 registers (3 waves per SIMD instead of 2).
@@ -59,6 +59,10 @@ def build(force=False, verbose=True):
     failed = False
     for src, p, ostamp, od in procs:
         out, _ = p.communicate()
+        remarks = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l)
+        out = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
+        with open(ostamp.replace(".stamp", ".res.txt"), "w") as fh:  # registers / scratch / LDS / occupancy of every kernel
+            fh.write(remarks + "\n")
         if out.strip() and verbose:
             print(out)
         if p.returncode != 0:

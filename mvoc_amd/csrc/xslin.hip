@@ -158,9 +158,11 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
     const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
-      // two passes over the register-resident row (mean, then sum of squared deviations), like F.layer_norm: the one-pass
-      // E[x^2] - mu^2 form loses the variance of rows whose mean is large against their spread (outlier channels)
-      float s1 = 0.f, s2 = 0.f;
+      // two passes over the register-resident row, like F.layer_norm: the mean first, then the moments of x - c with c the mean
+      // rounded to fp16 (packed fp16 subtraction: exact up to half an ulp of the small difference; fdot2 accumulates in fp32).
+      // The one-pass E[x^2] - mu^2 form loses the variance of rows whose mean is large against their spread; converting the
+      // row to fp32 for a textbook second pass made hipcc spill 350 registers in the 64-row form.
+      float s1 = 0.f;
 #pragma unroll
       for (int s = 0; s < NK; ++s)
 #pragma unroll
@@ -170,15 +172,22 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
         }
       s1 += __shfl_xor(s1, 32);
       const float mu = s1 / (float)K;
+      const half_t c16 = (half_t)mu;
+      const half2_t c2 = {c16, c16};
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int s = 0; s < NK; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dv = (float)xf[g][s][e] - mu;
-          s2 = __builtin_fmaf(dv, dv, s2);
+        for (int e = 0; e < 4; ++e) {
+          const half2_t v2 = {xf[g][s][2 * e], xf[g][s][2 * e + 1]};
+          const half2_t d2 = v2 - c2;
+          t1 = __builtin_amdgcn_fdot2(d2, one2, t1, false);
+          t2 = __builtin_amdgcn_fdot2(d2, d2, t2, false);
         }
-      s2 += __shfl_xor(s2, 32);
-      const float rs = rsqrtf(s2 / (float)K + p.eps);
+      t1 += __shfl_xor(t1, 32);
+      t2 += __shfl_xor(t2, 32);
+      const float dm = t1 / (float)K;  // mean of x - c: at most half an fp16 ulp of the mean
+      const float rs = rsqrtf(fmaxf(t2 / (float)K - dm * dm, 0.f) + p.eps);
 #pragma unroll
       for (int s = 0; s < NK; ++s)
 #pragma unroll

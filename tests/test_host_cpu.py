@@ -25,6 +25,37 @@ def test_abi_exports_every_declared_symbol():
     assert _ffi.lib.mvoc_groupnorm_workspace_bytes(16, 4096, 320, 32) > 0
 
 
+def test_no_kernel_of_the_library_uses_scratch():
+    """hipcc's kernel-resource-usage remarks of the build (mvoc_amd/build.py keeps them per object): no MFMA kernel of the
+    library may spill -- a spill in a K loop costs a scratch round trip per iteration and, next to LDS-DMA, a vmcnt(0) drain
+    (round 3: a textbook two-pass variance made the 64-row x-stationary linear spill 350 registers: +60 % on its launches,
+    caught only by the profile).  Every kernel must also fit the register budget its launch shape implies."""
+    from mvoc_amd import build
+    build.build(verbose=False)
+    csrc = os.path.join(REPO, "mvoc_amd", "csrc")
+    seen = {}
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".o.res.txt") or ".lab." in f:
+            continue
+        name = None
+        for line in open(os.path.join(csrc, f)):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                seen[name] = {}
+            for key in ("VGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill", "SGPRs Spill", "LDS Size [bytes/block]"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and name:
+                    seen[name][key] = int(m.group(1))
+    hot = [n for n in seen if any(k in n for k in ("gemm8_kernel", "gemm_glds_kernel", "xslin_kernel", "tfused_kernel", "flash_kernel",
+                                                    "tattn_kernel", "gn_apply", "gn_partial", "pnp_tokens_kernel"))]
+    assert len(hot) >= 40, sorted(seen)
+    for n in hot:
+        r = seen[n]
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (n, r)
+        assert r["VGPRs"] <= 256 and r["LDS Size [bytes/block]"] <= 163840, (n, r)
+
+
 def test_struct_layouts_match_header():
     """field order of the ctypes structs == field order in the header (both are read by the same kernel launcher)"""
     from mvoc_amd import _ffi
