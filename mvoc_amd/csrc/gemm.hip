@@ -887,7 +887,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   const int64_t lim = (int64_t)1 << 31;  // 32-bit MUBUF offsets, rows beyond the range read zeros
   const bool g8_ok = glds_ok && a.epi_lds && !(d->ln_rowsum && !d->ln_stats) && (a.n_store % 8 == 0) &&
                      rows_a * d->lda * 2 < lim && (d->a2 == nullptr || rows_a * d->lda2 * 2 < lim) &&
-                     (int64_t)d->n * d->k * 2 < lim;
+                     (int64_t)d->n * d->k * 2 < lim &&
+                     (int64_t)d->m * d->ldo * 2 < lim && (!d->resid || (int64_t)d->m * d->ldr * 2 < lim);  // (the 320-wide tile's epilogue)
   if (tile == 0 && g8_ok && d->m >= 4096 && d->k >= 512 && !(d->n <= 640 && d->k <= 640)) {
     // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
     // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last

@@ -57,7 +57,28 @@ __device__ __forceinline__ void g8_wait_vm() {
 // UPS: nearest-upsampled conv source (row not affine in the tap): own instantiation, the hot kernels carry no such code.
 // AFF: the source row of a staged pixel is affine in its index (plain, temporal, and 3x3 stride-1 same-size convs:
 //   row = m + (ky - 1) W + (kx - 1), validity in the tap masks): ONE row register serves the four staged rows of a lane.
-template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
+#ifndef G8_XT5_GROUP
+#define G8_XT5_GROUP 5
+#endif
+#ifdef MVOC_G8_STAMPS  // diagnostic build (tools/lab): s_memtime at the phase boundaries of block 0, waves 0 and 4
+__device__ unsigned long long g8_dbg[16];
+#define G8_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {                                   \
+      unsigned long long t_;                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      g8_dbg[(wave >> 2) * 8 + (i)] = t_;                                                             \
+    }                                                                                                 \
+  } while (0)
+#else
+#define G8_STAMP(i) do { } while (0)
+#endif
+
+// EPI: the epilogue forms the UNet uses as their own instantiations -- 1 plain (bias / row-add / residual), 2 LayerNorm fold,
+// 3 LayerNorm fold + GEGLU; 0 = everything, decided at run time.  The general epilogue is ~11 k instructions, executed once per
+// block and mostly branched over: with the K loop the kernel does not fit the instruction cache, and a pass's arithmetic took
+// 8-10 k ticks (phase stamps) -- as long as four K tiles -- for 64 values per lane; the plain form is 4 k instructions, 3 k ticks.
+template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF, int EPI>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   constexpr int XQ = XT * 16;            // channels per quadrant (and per wave group per X half-tile)
   constexpr int XH = 2 * XQ;             // rows of an X half-tile
@@ -79,6 +100,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  G8_STAMP(0);
   const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
   const int slice = (int)(logical0 % (unsigned)p.split_k);
   const unsigned logical = logical0 / (unsigned)p.split_k;
@@ -288,6 +310,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     g8_wait_vm<0>();
   }
   G8_BAR();
+  G8_STAMP(1);
   if (wr == 1) G8_BAR();  // group 1 falls one barrier behind
 
   // Yh0 slots: RETAIN -> the tile's parity (static); otherwise three rotating byte offsets (scalar)
@@ -358,6 +381,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
   if (t < nk) G8_KTILE(0, t);
   if (wr == 0) G8_BAR();  // group 0's balancing barrier: every wave is out of the K loop, the ring is free
+  G8_STAMP(2);
 
   const int g = fg;  // lane owns channels nq + 4 g .. + 3 of pixel (lane & 15) per 16 x 16 tile
   if (p.split_k > 1) {  // raw fp32 partials; bias / activation / residual happen in the reduce pass
@@ -378,8 +402,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------------
-  const bool geglu = p.act == MVOC_ACT_GEGLU;
-  const bool use_ln = p.ln_s != nullptr;
+  const bool geglu = EPI == 0 ? p.act == MVOC_ACT_GEGLU : EPI == 3;
+  const bool use_ln = EPI == 0 ? p.ln_s != nullptr : EPI >= 2;
   const bool use_bias = p.bias && !use_ln;
   constexpr int PITCH = XQ * 2 + 16;        // 144 / 176 B per pixel row of the wave's tile
   char* epi = smem + wave * (64 * PITCH);
@@ -398,9 +422,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
   for (int a = 0; a < 2; ++a) {  // (fully unrolled: the accumulators must be indexed statically)
     const int nq = n0 + wr * XH + a * XQ;  // first packed weight row of this pass
-    int nchunk, nbase;
+    const int nchunk = geglu ? 4 : XT * 2, nbase = geglu ? nq / 2 : nq;
+    // The pass's residual chunks are requested up front so that all of them are in flight behind the LDS round trip: XT == 4 the
+    // first half before the arithmetic below, the second half once the pass's accumulators have been consumed (registers); the
+    // 320-wide tile, which has no registers to spare while its accumulators are live, all ten after its LDS writes (a scheduling
+    // barrier keeps hipcc from hoisting them).
+    half8_t rres[XT == 4 ? 8 : 1];
+    auto resid_load = [&](int it) {
+      const int idx = lane + 64 * it;
+      const int px = idx / nchunk, c = idx - px * nchunk;
+      const int m = m0 + wc * 64 + px, n = nbase + c * 8;
+      rres[it] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (it < nchunk && m < p.M && n < p.n_store) rres[it] = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
+    };
+    if constexpr (XT == 4) {
+      if (p.resid) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) resid_load(it);
+      }
+    }
     if (geglu) {
-      if constexpr (XT == 4) {
+      if constexpr (XT == 4 && (EPI == 0 || EPI == 3)) {
         // packed rows: blocks of 64 = 32 value rows then 32 gate rows -> tiles i = 0, 1 are values, i + 2 their gates
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -436,8 +478,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             }
         }
       }
-      nchunk = 4;
-      nbase = nq / 2;
     } else {
 #pragma unroll
       for (int i = 0; i < XT; ++i) {
@@ -465,10 +505,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
               }
-              if (p.act == MVOC_ACT_SILU) {
+              if (EPI == 0 && p.act == MVOC_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
-              } else if (p.act == MVOC_ACT_GELU) {
+              } else if (EPI == 0 && p.act == MVOC_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
               }
@@ -478,33 +518,83 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
             *reinterpret_cast<half4_t*>(epi + (b * 32 + j * 16 + fr) * PITCH + (i * 16 + 4 * g) * 2) = o;
           }
       }
-      nchunk = XT * 2;
-      nbase = nq;
+    }
+    if constexpr (XT == 4) {
+      if (p.resid) {
+#pragma unroll
+        for (int it = 4; it < 8; ++it) resid_load(it);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (a wave's DS ops execute in order)
+    if (a == 0) G8_STAMP(6);
     // read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row
-    const int total = 64 * nchunk;
-#pragma unroll 2
-    for (int idx = lane; idx < total; idx += 64) {
-      const int px = idx / nchunk, c = idx - px * nchunk;
-      const int m = m0 + wc * 64 + px, n = nbase + c * 8;
-      half8_t v = *reinterpret_cast<const half8_t*>(epi + px * PITCH + c * 16);
-      if (m < p.M && n < p.n_store) {
+    // (two residual loads in flight per lane left the chip-wide output burst at 2.4 TB/s with every MFMA idle -- phase stamps:
+    // 2 x 22 k ticks per block against 2.3 k per K tile)
+    if constexpr (XT == 4) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        if (it < nchunk) {  // wave-uniform
+          const int idx = lane + 64 * it;
+          const int px = idx / nchunk, c = idx - px * nchunk;
+          const int m = m0 + wc * 64 + px, n = nbase + c * 8;
+          half8_t v = *reinterpret_cast<const half8_t*>(epi + px * PITCH + c * 16);
+          if (m < p.M && n < p.n_store) {
+            if (p.resid) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rres[it][e]);
+            }
+            if (G8_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n));
+            else *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+          }
+        }
+      }
+    } else {
+      // the 320-wide tile: branch-free through range-checked buffer instructions (rows >= M fall outside the resource, columns
+      // >= n_store get an out-of-range offset), one 32-bit offset per chunk instead of a 64-bit address and an exec mask, so the
+      // ten residual chunks of the pass fit in registers next to the other pass's accumulators and are all in flight together
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_r =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid ? p.resid : p.out), 0, p.resid ? (int)((size_t)p.M * p.ldr * 2) : 0, 0x00020000);
+      auto chunk_off = [&](int ln, int it, int ld) -> unsigned {
+        const int idx = ln + 64 * it;
+        const int px = idx / nchunk, c = idx - px * nchunk;
+        const int m = m0 + wc * 64 + px, n = nbase + c * 8;
+        return (it < nchunk && n < p.n_store) ? (unsigned)(m * ld + n) * 2u : G8_OOB;
+      };
+      u32x4 rr[XT * 2];
+      __builtin_amdgcn_sched_barrier(0);  // (not before the pass's accumulators are dead)
+#pragma unroll
+      for (int it = 0; it < XT * 2; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, chunk_off(lane, it, p.ldr), 0, 0);  // zeros without a residual
+      // (the index arithmetic is redone from an opaque copy of the lane id: shared with the loads above, hipcc keeps four
+      // values per chunk alive across the wait and spills them)
+      int lane2 = lane;
+      asm volatile("" : "+v"(lane2));
+#pragma unroll
+      for (int it = 0; it < XT * 2; ++it) {
+        const int idx = lane2 + 64 * it;
+        const int px = idx / nchunk, c = idx - px * nchunk;
+        half8_t v = *reinterpret_cast<const half8_t*>(epi + (it < nchunk ? px * PITCH + c * 16 : 0));
+        const half8_t r8 = __builtin_bit_cast(half8_t, rr[it]);
         if (p.resid) {
-          const half8_t r8 = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
         }
-        if (G8_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n));
-        else *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(lane2, it, p.ldo), 0, G8_NT_STORE ? 2 : 0);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
+    G8_STAMP(3 + a);
   }
+#ifdef MVOC_G8_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G8_STAMP(5);
+#endif
 }
 
 template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
 int launch8(const GemmArgs& a0, hipStream_t s) {
+  const int epi = a0.act == MVOC_ACT_NONE ? (a0.ln_s ? 2 : 1) : (a0.act == MVOC_ACT_GEGLU && a0.ln_s && XT == 4) ? 3 : 0;
   GemmArgs a = a0;
   constexpr int BX = XT * 64;
   a.n_tiles = (a.N + BX - 1) / BX;
@@ -514,7 +604,10 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm8: grid of %ld blocks", nblk);
     return -2;
   }
-  hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  if (epi == 1) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 1>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  else if (epi == 2) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 2>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  else if (epi == 3) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 3>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 0>), dim3((unsigned)nblk), dim3(512), 0, s, a);
   return mvoc_check_launch("gemm8_kernel");
 }
 
@@ -534,3 +627,9 @@ int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
   mvoc_set_error("gemm8: unsupported tile width %d", bx);
   return -1;
 }
+
+#ifdef MVOC_G8_STAMPS
+extern "C" int mvoc_g8_stamps_read(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g8_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
