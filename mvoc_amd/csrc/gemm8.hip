@@ -57,9 +57,6 @@ __device__ __forceinline__ void g8_wait_vm() {
 // UPS: nearest-upsampled conv source (row not affine in the tap): own instantiation, the hot kernels carry no such code.
 // AFF: the source row of a staged pixel is affine in its index (plain, temporal, and 3x3 stride-1 same-size convs:
 //   row = m + (ky - 1) W + (kx - 1), validity in the tap masks): ONE row register serves the four staged rows of a lane.
-#ifndef G8_XT5_GROUP
-#define G8_XT5_GROUP 5
-#endif
 #ifdef MVOC_G8_STAMPS  // diagnostic build (tools/lab): s_memtime at the phase boundaries of block 0, waves 0 and 4
 __device__ unsigned long long g8_dbg[16];
 #define G8_STAMP(i)                                                                                   \
@@ -423,24 +420,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   for (int a = 0; a < 2; ++a) {  // (fully unrolled: the accumulators must be indexed statically)
     const int nq = n0 + wr * XH + a * XQ;  // first packed weight row of this pass
     const int nchunk = geglu ? 4 : XT * 2, nbase = geglu ? nq / 2 : nq;
-    // The pass's residual chunks are requested up front so that all of them are in flight behind the LDS round trip: XT == 4 the
-    // first half before the arithmetic below, the second half once the pass's accumulators have been consumed (registers); the
-    // 320-wide tile, which has no registers to spare while its accumulators are live, all ten after its LDS writes (a scheduling
-    // barrier keeps hipcc from hoisting them).
-    half8_t rres[XT == 4 ? 8 : 1];
-    auto resid_load = [&](int it) {
-      const int idx = lane + 64 * it;
-      const int px = idx / nchunk, c = idx - px * nchunk;
-      const int m = m0 + wc * 64 + px, n = nbase + c * 8;
-      rres[it] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      if (it < nchunk && m < p.M && n < p.n_store) rres[it] = *reinterpret_cast<const half8_t*>(p.resid + (size_t)m * p.ldr + n);
-    };
-    if constexpr (XT == 4) {
-      if (p.resid) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) resid_load(it);
-      }
-    }
     if (geglu) {
       if constexpr (XT == 4 && (EPI == 0 || EPI == 3)) {
         // packed rows: blocks of 64 = 32 value rows then 32 gate rows -> tiles i = 0, 1 are values, i + 2 their gates
@@ -519,39 +498,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
           }
       }
     }
-    if constexpr (XT == 4) {
-      if (p.resid) {
-#pragma unroll
-        for (int it = 4; it < 8; ++it) resid_load(it);
-      }
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (a wave's DS ops execute in order)
     if (a == 0) G8_STAMP(6);
-    // read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row
-    // (two residual loads in flight per lane left the chip-wide output burst at 2.4 TB/s with every MFMA idle -- phase stamps:
-    // 2 x 22 k ticks per block against 2.3 k per K tile)
-    if constexpr (XT == 4) {
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        if (it < nchunk) {  // wave-uniform
-          const int idx = lane + 64 * it;
-          const int px = idx / nchunk, c = idx - px * nchunk;
-          const int m = m0 + wc * 64 + px, n = nbase + c * 8;
-          half8_t v = *reinterpret_cast<const half8_t*>(epi + px * PITCH + c * 16);
-          if (m < p.M && n < p.n_store) {
-            if (p.resid) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rres[it][e]);
-            }
-            if (G8_NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n));
-            else *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ldo + n) = v;
-          }
-        }
-      }
-    } else {
-      // the 320-wide tile: branch-free through range-checked buffer instructions (rows >= M fall outside the resource, columns
-      // >= n_store get an out-of-range offset), one 32-bit offset per chunk instead of a 64-bit address and an exec mask, so the
-      // ten residual chunks of the pass fit in registers next to the other pass's accumulators and are all in flight together
+    // Read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row; residual added, stored.
+    // Branch-free through range-checked buffer instructions (rows >= M fall outside the resource, columns >= n_store get an
+    // out-of-range offset): one 32-bit offset per chunk instead of a 64-bit address and an exec mask, so that ALL residual
+    // chunks of the pass are in flight together (two loads in flight per lane left the chip-wide output burst at 2.4 TB/s with
+    // every MFMA idle -- phase stamps: 2 x 22 k ticks per block against 2.3 k per K tile), even beside the other pass's
+    // accumulators of the 320-wide tile.
+    {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_r =
