@@ -889,17 +889,19 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                      rows_a * d->lda * 2 < lim && (d->a2 == nullptr || rows_a * d->lda2 * 2 < lim) &&
                      (int64_t)d->n * d->k * 2 < lim &&
                      (int64_t)d->m * d->ldo * 2 < lim && (!d->resid || (int64_t)d->m * d->ldr * 2 < lim);  // (the 320-wide tile's epilogue)
-  if (tile == 0 && g8_ok && d->m >= 4096 && d->k >= 512 && !(d->n <= 640 && d->k <= 640)) {
+  if (tile == 0 && g8_ok && d->m >= 1024 && d->k >= 256) {
     // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
     // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last
-    // tile of a row and CUs idle in the last wave of blocks (one block per CU).  The 320-wide form runs within ~3 % of the 256-wide
-    // one per flop.
+    // tile of a row and CUs idle in the last wave of blocks (one block per CU).  Per flop the 320-wide form runs at ~0.85 of the
+    // 256-wide one (phase stamps: 3 430 against 2 300 ticks per K tile for 1.25 x the channels; re-reading Yh0 costs it the rest).
+    // (Until the epilogue forms were split -- gemm8.hip, EPI -- the short-K projections, n and k <= 640, were faster on the
+    // general tiles; with the 3 k-tick plain epilogue they are 30-45 % faster here.)
     auto eff = [&](int bx, double rate) {
       const int64_t nt = (d->n + bx - 1) / bx, blocks = ((d->m + 255) / 256) * nt;
       return (double)d->n / (double)(nt * bx) * (double)blocks / (double)(((blocks + 255) / 256) * 256) * rate;
     };
     const double e81 = eff(256, 1.0);
-    const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.97) : 0.0;
+    const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.85) : 0.0;
     if (e81 >= 0.55 || e82 >= 0.55) {
       tile = e82 > e81 ? 82 : 81;
     } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
