@@ -144,9 +144,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[T
 // row-add vectors are per channel there: broadcast loads), the fp16-rounded result is parked in a wave-private LDS
 // tile [32 pixels][TO*32 channels] (pitch + 16 B: conflict-free 8-byte writes), read back as 16-byte row chunks, the
 // residual added, stored.  `lds` = this wave's region (32 * (TO*64+16) bytes), free once every wave left the K loop.
-template <int WN, int WM, int TN, int TM, bool GEGLU>
+// EPI 1: bias / row-add / residual only (no LayerNorm fold, no activation) -- the form most launches take, as its own code
+template <int WN, int WM, int TN, int TM, bool GEGLU, int EPI = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&acc)[TN][TM], int n0, int m0, int wn, int wm,
-                                                  int r, int h, int lane, char* lds, const float* lnstat) {
+                                                  int r, int h, int lane, char* lds, const float* lnstat_) {
+  const float* lnstat = EPI == 1 ? nullptr : lnstat_;
   constexpr bool geglu = GEGLU;
   constexpr int TO = GEGLU ? TN / 2 : TN;  // 32-channel output tiles per wave
   const bool use_bias = p.bias && !lnstat;
@@ -221,10 +223,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& p, f32x16 (&ac
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
             }
-            if (p.act == MVOC_ACT_SILU) {
+            if (EPI != 1 && p.act == MVOC_ACT_SILU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
-            } else if (p.act == MVOC_ACT_GELU) {
+            } else if (EPI != 1 && p.act == MVOC_ACT_GELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
             }
@@ -449,7 +451,7 @@ __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 // PLAIN = 1: single-source plain linear (no taps, no second source, no upsampling) -- the per-K-step address work is one
 // pointer bump per LDS-DMA instead of the general gather bookkeeping (the K <= 1280 projections were VALU-issue bound:
 // ~22 non-MFMA instructions per MFMA in the general loop)
-template <int WN, int WM, int TN, int TM, int NST, int PF = 0, int BKK = 64, int PLAIN = 0>
+template <int WN, int WM, int TN, int TM, int NST, int PF = 0, int BKK = 64, int PLAIN = 0, int EPI = 0>
 __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p) {
   static_assert(BKK == 64 || BKK == 32, "K step of 64 (128-byte staged rows) or 32 (64-byte rows)");
   constexpr int NCH = BKK / 8;           // 16-byte chunks per row
@@ -723,6 +725,11 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     return;
   }
+  if constexpr (EPI == 1) {  // (the host launches this form only for epi_lds launches without LayerNorm fold / activation)
+    __syncthreads();
+    gemm_epilogue_lds<WN, WM, TN, TM, false, 1>(p, acc, n0, m0, wn, wm, r, h, lane, smem + wave * EPI_BYTES, nullptr);
+    return;
+  }
   {
     if (p.epi_lds && !(p.ln_s && !p.ln_stats)) {
       __syncthreads();  // every wave is out of the K loop: the staging buffers are free
@@ -804,6 +811,16 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
   if (nblk <= 0 || nblk > 0x7fffffffL) {
     mvoc_set_error("gemm: grid of %ld blocks", nblk);
     return -2;
+  }
+  // The epilogue of these kernels covers every activation / LayerNorm / GEGLU form at run time: ~25 k instructions behind a
+  // 40-instruction K loop, executed once per block, far beyond the instruction cache (gemm8.hip, EPI, has the measurement).
+  // The tile shapes that carry the denoising loop's small launches get the plain form as an own instantiation.
+  constexpr bool HOT = (WN == 2 && WM == 2 && TN == 2 && TM == 2) || (WN == 1 && WM == 4 && TM == 1 && (TN == 2 || TN == 5));
+  if (HOT && a.epi_lds && !a.ln_s && a.act == MVOC_ACT_NONE && a.split_k == 1) {
+    if constexpr (HOT) {
+      hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK, PLAIN, 1>), dim3((unsigned)nblk), dim3(WN * WM * 64), 0, s, a);
+      return mvoc_check_launch("gemm_glds_kernel (plain epilogue)");
+    }
   }
   hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK, PLAIN>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
   if (a.split_k > 1) {

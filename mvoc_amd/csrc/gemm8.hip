@@ -295,8 +295,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   };
 
   // ---- prologue: K tile 0 landed, {Yh0, Xh0, Yh1} of tile 1 in flight ------------------------------------------------------
+  // (the weight halves first: they need no gather geometry, so their first-byte latency runs beside y_prepare's index arithmetic)
+  G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_X(1, OX1, xso1);
+  __builtin_amdgcn_sched_barrier(0);
   y_prepare();
-  G8_ISSUE_Y(0, OY0); G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_Y(1, OY1); G8_ISSUE_X(1, OX1, xso1);
+  G8_ISSUE_Y(0, OY0); G8_ISSUE_Y(1, OY1);
   y_advance();
   if (nk > 1) {
     y_prepare();
