@@ -1,6 +1,6 @@
 // Phase timing of the product eight-phase GEMM (diagnostic library built with -DMVOC_G8_STAMPS): s_memtime at kernel entry,
 // end of prologue, end of the K loop, end of each epilogue pass, stores drained -- block 0, waves 0 (group 0) and 4 (group 1).
-//   usage: g8_stamps M N K tile(81|82) resid(0|1)
+//   usage: g8_stamps M N K tile(81|82) resid(0|1) [form: 0 plain, 2 LayerNorm fold, 3 LayerNorm fold + GEGLU]
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -30,7 +30,13 @@ int main(int argc, char** argv) {
   memset(&d, 0, sizeof(d));
   d.a = A; d.w = W; d.out = O; d.m = M; d.n = N; d.k = K; d.n_store = N; d.ldo = N; d.lda = K; d.c1 = K; d.cin = K;
   d.a_mode = 0; d.tile = tile; d.split_k = 1;
-  if (use_r) { d.resid = R; d.ldr = N; }
+  const int form = argc > 6 ? atoi(argv[6]) : 0;
+  float *LS, *LC, *ST;
+  CK(hipMalloc(&LS, (size_t)N * 4)); CK(hipMalloc(&LC, (size_t)N * 4)); CK(hipMalloc(&ST, (size_t)M * 8));
+  CK(hipMemset(LS, 0, (size_t)N * 4)); CK(hipMemset(LC, 0, (size_t)N * 4)); CK(hipMemset(ST, 0, (size_t)M * 8));
+  if (form >= 2) { d.ln_rowsum = LS; d.ln_bias = LC; d.ln_stats = ST; d.ln_eps = 1e-5f; }
+  if (form == 3) { d.act = MVOC_ACT_GEGLU; d.n_store = N / 2; d.ldo = N / 2; }
+  if (use_r) { d.resid = R; d.ldr = d.ldo; }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) if (mvoc_gemm_f16(&d, 0)) { fprintf(stderr, "%s\n", mvoc_last_error()); return 1; }
@@ -43,7 +49,7 @@ int main(int argc, char** argv) {
   if (mvoc_g8_stamps_read(t)) { fprintf(stderr, "no stamps\n"); return 1; }
   const int bx = tile == 82 ? 320 : 256;
   const long blocks = (long)((M + 255) / 256) * ((N + bx - 1) / bx);
-  printf("M=%d N=%d K=%d tile %d resid %d: %.1f us per launch, %.0f TF/s, %ld blocks = %.2f rounds, %d K tiles\n", M, N, K, tile, use_r,
+  printf("M=%d N=%d K=%d tile %d resid %d form %d: %.1f us per launch, %.0f TF/s, %ld blocks = %.2f rounds, %d K tiles\n", M, N, K, tile, use_r, form,
          ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) * 1e-12, blocks, blocks / 256.0, K / 64);
   for (int g = 0; g < 2; ++g) {
     const unsigned long long* s = t + 8 * g;
