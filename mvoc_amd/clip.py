@@ -130,19 +130,21 @@ class _Tower:
         return s
 
     def init_random(self, seed=4321):
-        """seeded synthetic weights of the exact architecture (no checkpoint is reachable in the build environment)"""
-        g = torch.Generator().manual_seed(seed)
+        """seeded synthetic weights of the exact architecture (no checkpoint is reachable in the build environment), generated
+        on the device (ViT-H is 630 M parameters: 15 s per tower through the CPU generator, 0.1 s here)"""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        dev = self.device
         sd = {}
         for k, shp in self.param_shapes().items():
             if "norm" in k or "layrnorm" in k:
-                t = (1.0 if k.endswith("weight") else 0.0) + 0.1 * (torch.rand(shp, generator=g) * 2 - 1)
+                t = (1.0 if k.endswith("weight") else 0.0) + 0.1 * (torch.rand(shp, generator=g, device=dev) * 2 - 1)
             elif k.endswith("bias"):
-                t = 0.05 * (torch.rand(shp, generator=g) * 2 - 1)
+                t = 0.05 * (torch.rand(shp, generator=g, device=dev) * 2 - 1)
             elif "embedding" in k and not k.endswith("patch_embedding.weight"):
-                t = 0.5 * torch.randn(shp, generator=g)
+                t = 0.5 * torch.randn(shp, generator=g, device=dev)
             else:
                 fan = int(np.prod(shp[1:]))
-                t = (torch.rand(shp, generator=g) * 2 - 1) * math.sqrt(3.0 / fan)
+                t = (torch.rand(shp, generator=g, device=dev) * 2 - 1) * math.sqrt(3.0 / fan)
                 if k.endswith("out_proj.weight") or k.endswith("fc2.weight"):
                     t *= 0.5
             sd[k] = t.to(H16)
