@@ -123,6 +123,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
   const unsigned xh1 = (unsigned)XQ * (unsigned)p.K * 2u;  // byte distance of half 1's rows
   int xso0 = kbeg * 2, xso1 = kbeg * 2;  // scalar byte offsets of the two X streams
+  const int wbase = wave * 1024;
+#define G8_LDS(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
+  // (half 1's offset is formed at issue time by an opaque add: loop-invariant, hipcc would otherwise keep PXM more registers)
+  auto x_off = [&](int h, int q) -> unsigned {
+    if (!h || YP) return xoff[q] + (h ? xh1 : 0u);
+    unsigned r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(xh1), "v"(xoff[q]));
+    return r;
+  };
+#define G8_ISSUE_X(h, base, so)                                                                                         \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < PXM; ++q) if (q < npx)                                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, G8_LDS((base) + wbase + q * 8192), 16, (int)x_off(h, q), so, 0, 0); \
+    so += 128;                                                                                                          \
+  } while (0)
+  // The weight halves of K tile 0 go out HERE: the gather geometry below (two integer divisions and nine tap tests per staged
+  // row) is ~900 instructions -- with it in front, the first DMA left the wave 3.5 k ticks after kernel entry (phase stamps),
+  // one and a half K tiles of nothing.  vmcnt arithmetic unchanged: all of tile 0 is still issued before any of tile 1.
+  G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_X(1, OX1, xso1);
+  __builtin_amdgcn_sched_barrier(0);
   // activation side: per staged row a source-row index for tap (0,0) and a mask of the taps inside the image (two 16-bit
   // masks per register)
   int rowoff[AFF ? 1 : 2][AFF ? 1 : 2];
@@ -215,21 +235,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if (ych0 >= p.cin) { ych0 = 0; ++ytap; yre = true; }
   };
 
-  const int wbase = wave * 1024;
-#define G8_LDS(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
-  // (half 1's offset is formed at issue time by an opaque add: loop-invariant, hipcc would otherwise keep PXM more registers)
-  auto x_off = [&](int h, int q) -> unsigned {
-    if (!h || YP) return xoff[q] + (h ? xh1 : 0u);
-    unsigned r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(xh1), "v"(xoff[q]));
-    return r;
-  };
-#define G8_ISSUE_X(h, base, so)                                                                                         \
-  do {                                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < PXM; ++q) if (q < npx)                                                        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, G8_LDS((base) + wbase + q * 8192), 16, (int)x_off(h, q), so, 0, 0); \
-    so += 128;                                                                                                          \
-  } while (0)
 #define G8_ISSUE_Y(h, base)                                                                                             \
   do {                                                                                                                  \
     _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                       \
@@ -295,9 +300,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   };
 
   // ---- prologue: K tile 0 landed, {Yh0, Xh0, Yh1} of tile 1 in flight ------------------------------------------------------
-  // (the weight halves first: they need no gather geometry, so their first-byte latency runs beside y_prepare's index arithmetic)
-  G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_X(1, OX1, xso1);
-  __builtin_amdgcn_sched_barrier(0);
   y_prepare();
   G8_ISSUE_Y(0, OY0); G8_ISSUE_Y(1, OY1);
   y_advance();
