@@ -53,8 +53,8 @@ int main(int argc, char** argv) {
          ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) * 1e-12, blocks, blocks / 256.0, K / 64);
   for (int g = 0; g < 2; ++g) {
     const unsigned long long* s = t + 8 * g;
-    printf("  group %d (ticks): prologue %llu (tile 0 issued after %llu) | K loop %llu (%.0f per tile) | epilogue pass 0 %llu (arithmetic + LDS write %llu, readback + stores %llu) | pass 1 %llu | store drain %llu | block %llu\n", g,
-           s[1] - s[0], s[7] - s[0], s[2] - s[1], (double)(s[2] - s[1]) / (K / 64), s[3] - s[2], s[6] - s[2], s[3] - s[6], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
+    printf("  group %d (ticks): prologue %llu | K loop %llu (%.0f per tile) | epilogue pass 0 %llu (arithmetic + LDS write %llu, readback + stores %llu) | pass 1 %llu | store drain %llu | block %llu\n", g,
+           s[1] - s[0], s[2] - s[1], (double)(s[2] - s[1]) / (K / 64), s[3] - s[2], s[6] - s[2], s[3] - s[6], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
   }
   return 0;
 }
