@@ -357,6 +357,29 @@ def test_linear_production_tiles_exact(ops, m, n, k, tile):
     assert torch.equal(out.float().cpu(), ref), f"tile {tile}"
 
 
+@pytest.mark.parametrize("tile", [81, 82])
+@pytest.mark.parametrize("m,n,ns,k", [(1000, 352, 328, 640), (2309, 672, 672, 576), (4099, 1312, 1288, 512)])
+def test_g8_readback_ragged_rows_and_column_views(ops, m, n, ns, k, tile):
+    """the eight-phase tiles' branch-free epilogue readback (range-checked buffer loads / stores): rows that end inside a block,
+    a last column tile that is mostly outside n, fewer columns stored than computed (n_store < n), and `out` / `resid` that are
+    column slices of wider tensors (ldo, ldr > n_store) -- nothing may be written outside the slice; exact on integer operands"""
+    g = torch.Generator().manual_seed(m + n + k + tile)
+    x, w = _ints(g, (m, k)), _ints(g, (n, k))
+    w[torch.rand(w.shape, generator=g) < 0.5] = 0
+    b = _ints(g, (n,), -4, 4)
+    rwide = _ints(g, (m, ns + 24), -4, 4)
+    ref = (x @ w.t() + b)[:, :ns] + rwide[:, 8:8 + ns]
+    owide = torch.full((m + 3, ns + 40), 7.0).half().cuda()      # sentinel everywhere, 3 extra rows below
+    rdev = dev(rwide)
+    ops.linear(dev(x), dev(w), dev(b), resid=rdev[:, 8:8 + ns], out=owide[:m, 16:16 + ns], n_store=ns, tile=tile, split_k=1)
+    torch.cuda.synchronize()
+    got = owide.float().cpu()
+    assert torch.equal(got[:m, 16:16 + ns], ref), f"tile {tile}: {(got[:m, 16:16 + ns] != ref).sum().item()} wrong outputs"
+    untouched = got.clone()
+    untouched[:m, 16:16 + ns] = 7.0
+    assert bool((untouched == 7.0).all()), "the epilogue wrote outside the output slice"
+
+
 @pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67, 81])
 @pytest.mark.parametrize("m,c,inner", [(16384, 320, 1280), (4096, 1280, 5120)])
 def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
