@@ -1,6 +1,6 @@
 // Phase timing of the product eight-phase GEMM (diagnostic library built with -DMVOC_G8_STAMPS): s_memtime at kernel entry,
 // end of prologue, end of the K loop, end of each epilogue pass, stores drained -- block 0, waves 0 (group 0) and 4 (group 1).
-//   usage: g8_stamps M N K tile(81|82) resid(0|1) [form: 0 plain, 2 LayerNorm fold, 3 LayerNorm fold + GEGLU]
+//   usage: g8_stamps M N K tile(81|82) resid(0|1) [form: 0 plain, 2 LayerNorm fold, 3 LayerNorm fold + GEGLU; + 8: with bias and a per-256-row row-add]
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdio.h>
@@ -30,7 +30,12 @@ int main(int argc, char** argv) {
   memset(&d, 0, sizeof(d));
   d.a = A; d.w = W; d.out = O; d.m = M; d.n = N; d.k = K; d.n_store = N; d.ldo = N; d.lda = K; d.c1 = K; d.cin = K;
   d.a_mode = 0; d.tile = tile; d.split_k = 1;
-  const int form = argc > 6 ? atoi(argv[6]) : 0;
+  const int form0 = argc > 6 ? atoi(argv[6]) : 0;
+  const int form = form0 & 7;
+  half_t *B, *RA;
+  CK(hipMalloc(&B, (size_t)N * 2)); CK(hipMalloc(&RA, (size_t)(M / 256 + 1) * N * 2));
+  fill<<<64, 256>>>(B, (size_t)N, 4u); fill<<<2048, 256>>>(RA, (size_t)(M / 256 + 1) * N, 5u);
+  if (form0 & 8) { d.bias = B; d.rowadd = RA; d.ld_rowadd = N; d.rowadd_div = 256; }
   float *LS, *LC, *ST;
   CK(hipMalloc(&LS, (size_t)N * 4)); CK(hipMalloc(&LC, (size_t)N * 4)); CK(hipMalloc(&ST, (size_t)M * 8));
   CK(hipMemset(LS, 0, (size_t)N * 4)); CK(hipMemset(LC, 0, (size_t)N * 4)); CK(hipMemset(ST, 0, (size_t)M * 8));
