@@ -77,9 +77,18 @@ typedef struct mvoc_gemm_desc {
                            encoder, diffusers Downsample2D(padding=0)) */
   const void* ln_stats; /* optional {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (one read of the rows, shared by
                            every n-tile); NULL: each block accumulates the statistics of its rows in the K loop */
+  void* chan_sums;      /* optional REQUEST, fp32 [ceil(m / 256)][n_store][2]: per 256-row slab and output channel, the sum and the
+                           sum of squares of the values this call stores (fp16-rounded, residual included) -- the first pass of the
+                           GroupNorm that reads `out` next (F.group_norm at pnp_utils.py:909-910, 953-965, 1048-1051, 185-188),
+                           taken from the producer's epilogue instead of a separate read of the tensor.  Written only when the
+                           launch runs on the eight-phase tiles without split-K and without activation: ask
+                           mvoc_gemm_chan_sums_written() after the call; when it answers 0 the buffer is untouched and the
+                           consumer computes its own statistics (mvoc_groupnorm_f16 without chan_sums). */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
+/* 1 when this thread's most recent mvoc_gemm_f16 call wrote its descriptor's chan_sums */
+int mvoc_gemm_chan_sums_written(void);
 /* scratch for the deterministic split-K form of a launch: the most the auto policy uses is 8 slices of m*n fp32
  * partials; 0 when the policy would never split this shape (m > 8192 or k < 2048).  Passing no workspace is always valid:
  * the launch then runs unsplit. */
@@ -101,6 +110,11 @@ typedef struct mvoc_attn_desc {
    * pipeline_i2vgen_xl.py:552-737 encode_prompt -> CLIPTextModel) */
   int32_t head_dim, causal;
   float scale;
+  /* paired form (head_dim 64): a second value tensor / output with the layout of v / out that attends with the SAME q and k --
+   * the PnP destination chunks after Q/K injection (pnp_utils.py:664-668 assigns one blended q / k to both the unconditional and
+   * the conditional chunk; only their v differ).  NULL: plain attention.  Results equal two plain calls bit for bit. */
+  const void* v2;
+  void* out2;
 } mvoc_attn_desc;
 
 /* spatial self-attention and image/text cross-attention (flash-style, K/V tiles LDS-staged) */

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("nimg", i32), ("hout", i32), ("wout", i32), ("hsrc", i32), ("wsrc", i32), ("stride", i32),
                 ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
                 ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("ln_rowsum", vp), ("ln_bias", vp),
-                ("ln_eps", f32), ("pad_mode", i32), ("ln_stats", vp)]
+                ("ln_eps", f32), ("pad_mode", i32), ("ln_stats", vp), ("chan_sums", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -36,7 +36,7 @@ class AttnDesc(C.Structure):
                 ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ts", i64), ("v_bs", i64), ("v_ts", i64),
                 ("o_bs", i64), ("o_ts", i64),
                 ("nbatch", i32), ("heads", i32), ("tq", i32), ("tk", i32), ("kv_bdiv", i32),
-                ("head_dim", i32), ("causal", i32), ("scale", C.c_float)]
+                ("head_dim", i32), ("causal", i32), ("scale", C.c_float), ("v2", vp), ("out2", vp)]
 
 
 class TAttnDesc(C.Structure):

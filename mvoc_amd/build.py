@@ -21,7 +21,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # gemm: neutral for the 32-row-per-wave tiles (same speed, no accvgpr traffic), required by the 64-row-per-wave tiles
 # (160 / 128 accumulator registers + operands fit 256 unified registers only in this form -> 2 waves per SIMD).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "gemm8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "tfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # gemm8: loop headers on 64-byte boundaries -- the K loop's speed depends on where its first instruction falls (the
+               # guide's code-placement note); pinned so that edits elsewhere in the kernel do not move it
+               "gemm8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-falign-loops=64"], "tfused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                "xslin.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

@@ -33,6 +33,7 @@ struct AttnArgs {
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
   int nbatch, heads, tq, tk, kv_bdiv, causal;
   float scale_log2;
+  long v2_off, o2_off;  // NV == 2: element offsets of the pair's second V / output (same Q and K)
 };
 
 __device__ __forceinline__ int vt_slot_group(int key) {  // 16-byte group (8 slots) of a key inside its 32-key tile
@@ -40,11 +41,20 @@ __device__ __forceinline__ int vt_slot_group(int key) {  // 16-byte group (8 slo
 }
 __device__ __forceinline__ int vt_slot_elem(int key) { return ((key >> 3) & 1) * 4 + (key & 3); }
 
-template <int D>  // head dim: 64 (the UNet), 96 (CLIP ViT-H's 80, zero-padded by the projection weights)
+// The running maximum is DEFERRED: the accumulators are rescaled only when some query's maximum has grown by more than 2^FLASH_THR
+// since the last rescale (wave-uniform test), so P = exp2(c (s - m)) may reach 2^8 instead of 1 -- exact in fp16's range, same
+// relative rounding, fp32 sums.  With the plain "did any maximum grow" test 32 queries per wave rescaled on ~65 % of the 64 tiles
+// of a 4096-key row (32 multiplies + an exponential per lane each time); with the threshold on the first tile or two only.
+constexpr float FLASH_THR = 8.0f;
+
+// NV = 2: TWO value tensors attend with the same Q and K (the PnP destination pair: pnp_utils.py:664-668 writes one blended
+// q / k into both the unconditional and the conditional chunk, so softmax(q k^T) is computed once and multiplied into both V's;
+// per tile 16 more MFMAs instead of a second S^T + softmax + PV pass).  Outputs are bit-identical to two NV = 1 launches.
+template <int D, int NV>  // head dim: 64 (the UNet), 96 (CLIP ViT-H's 80, zero-padded by the projection weights)
 __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   constexpr int KPITCH = FlashPitch<D>::K, VPITCH = FlashPitch<D>::V;
   constexpr int ND = D / 16, NT = D / 32, CPK = D / 8, NCH = 64 * CPK / 256;  // k steps, output tiles, 16-byte chunks per key / thread
-  __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + 64 * VPITCH];
+  __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + NV * 64 * VPITCH];
   char* Ks = smem;
   char* Vs = smem + 64 * KPITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,15 +71,17 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * D;
   const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * D;
 
-  f32x16 ot[NT];
+  f32x16 ot[NV][NT];
 #pragma unroll
-  for (int dt = 0; dt < NT; ++dt)
+  for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) ot[dt][e] = 0.f;
+    for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ot[v][dt][e] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
 
   const int ntiles = (p.tk + 63) / 64;
-  half8_t kreg[NCH], vreg[NCH];
+  half8_t kreg[NCH], vreg[NV][NCH];
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int kt) {
 #pragma unroll
@@ -77,10 +89,12 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
       const int c = tid + i * 256;
       const int key = kt * 64 + c / CPK, dc = c % CPK;
       kreg[i] = zero8;
-      vreg[i] = zero8;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) vreg[v][i] = zero8;
       if (key < p.tk) {
         kreg[i] = *reinterpret_cast<const half8_t*>(kb + (long)key * p.k_ts + dc * 8);
-        vreg[i] = *reinterpret_cast<const half8_t*>(vb + (long)key * p.v_ts + dc * 8);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) vreg[v][i] = *reinterpret_cast<const half8_t*>(vb + v * p.v2_off + (long)key * p.v_ts + dc * 8);
       }
     }
   };
@@ -92,7 +106,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
       const int c = tid + i * 256;
       const int key = c / CPK, dc = c % CPK;
       *reinterpret_cast<half8_t*>(Ks + key * KPITCH + dc * 16) = kreg[i];
-      *reinterpret_cast<half8_t*>(Vs + key * VPITCH + dc * 16) = vreg[i];  // row-major; transposed on the read (below)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        *reinterpret_cast<half8_t*>(Vs + v * 64 * VPITCH + key * VPITCH + dc * 16) = vreg[v][i];  // row-major; transposed on the read (below)
     }
     __syncthreads();
     if (kt + 1 < ntiles) gload(kt + 1);
@@ -130,15 +146,17 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (__any(mx > mrun)) {  // wave-uniform: rescale the running state only when some query's maximum grew
+    if (__any((mx - mrun) * p.scale_log2 > FLASH_THR)) {  // wave-uniform; always on the first tile (mrun = -inf)
       const float mnew = fmaxf(mrun, mx);
       const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2);
       mrun = mnew;
       lrun *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt)
+      for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ot[dt][e] *= alpha;
+        for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ot[v][dt][e] *= alpha;
     }
     const float mc = mrun * p.scale_log2;
     float ps = 0.f;
@@ -165,33 +183,38 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
         // accumulator's k order is two runs of 4 consecutive keys (32t + 16s + 4h + {0..3} and + 8): two reads.
         const int krow = 32 * t + 16 * s + 4 * h + ((lane & 15) >> 2);
 #pragma unroll
-        for (int dt = 0; dt < NT; ++dt) {
-          const char* va = Vs + krow * VPITCH + (32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-          const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
-          const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 8 * VPITCH));
-          half8_t vf;
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            vf[e] = (half_t)lo[e];
-            vf[4 + e] = (half_t)hi[e];
+          for (int dt = 0; dt < NT; ++dt) {
+            const char* va = Vs + v * 64 * VPITCH + krow * VPITCH + (32 * dt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+            const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
+            const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 8 * VPITCH));
+            half8_t vf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              vf[e] = (half_t)lo[e];
+              vf[4 + e] = (half_t)hi[e];
+            }
+            ot[v][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[v][dt], 0, 0, 0);
           }
-          ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
-        }
       }
   }
   const float ltot = lrun + __shfl_xor(lrun, 32);
   const float inv = 1.0f / ltot;
   if (q0 + r < p.tq) {
-    half_t* op = p.out + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * D;
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt)
+    for (int v = 0; v < NV; ++v) {
+      half_t* op = p.out + v * p.o2_off + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * D;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        half4_t o;
+      for (int dt = 0; dt < NT; ++dt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[dt][q * 4 + e] * inv);
-        *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h) = o;
-      }
+        for (int q = 0; q < 4; ++q) {
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[v][dt][q * 4 + e] * inv);
+          *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h) = o;
+        }
+    }
   }
 }
 
@@ -323,10 +346,21 @@ extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   a.causal = d->causal;
   a.scale_log2 = (d->scale > 0.f ? d->scale : (hd == 64 ? 0.125f : 1.0f / sqrtf((float)hd))) * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  MvocProfScope prof(MVOC_FAM_FLASH, s, 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * hd);
+  // (work = what the reference computes: the paired form stands for two attentions)
+  MvocProfScope prof(MVOC_FAM_FLASH, s, (d->v2 ? 2.0 : 1.0) * 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * hd);
   dim3 grid((d->tq + 127) / 128, d->heads, d->nbatch);
-  if (hd == 64) hipLaunchKernelGGL(flash_kernel<64>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(flash_kernel<96>, grid, dim3(256), 0, s, a);
+  a.v2_off = a.o2_off = 0;
+  if (d->v2) {
+    MVOC_REQUIRE(d->out2 && hd == 64, -2, "flash_attn: the paired form needs out2 and head_dim 64");
+    a.v2_off = (const half_t*)d->v2 - a.v;
+    a.o2_off = (half_t*)d->out2 - a.out;
+    MVOC_REQUIRE(a.v2_off % 8 == 0 && a.o2_off % 4 == 0, -2, "flash_attn: v2 / out2 must keep 16-byte alignment");
+    hipLaunchKernelGGL((flash_kernel<64, 2>), grid, dim3(256), 0, s, a);
+  } else if (hd == 64) {
+    hipLaunchKernelGGL((flash_kernel<64, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((flash_kernel<96, 1>), grid, dim3(256), 0, s, a);
+  }
   return mvoc_check_launch("flash_kernel");
 }
 

@@ -837,7 +837,11 @@ extern "C" size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   return (size_t)8 * (size_t)m * (size_t)n * sizeof(float);
 }
 
+namespace { thread_local int g_sums_written = 0; }
+extern "C" int mvoc_gemm_chan_sums_written(void) { return g_sums_written; }
+
 extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
+  g_sums_written = 0;
   MVOC_REQUIRE(d && d->a && d->w && d->out, -1, "gemm: null operand");
   MVOC_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, -1, "gemm: empty problem m=%ld n=%ld k=%ld", (long)d->m, (long)d->n,
                (long)d->k);
@@ -905,7 +909,11 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   const bool g8_ok = glds_ok && a.epi_lds && !(d->ln_rowsum && !d->ln_stats) && (a.n_store % 8 == 0) &&
                      rows_a * d->lda * 2 < lim && (d->a2 == nullptr || rows_a * d->lda2 * 2 < lim) &&
                      (int64_t)d->n * d->k * 2 < lim &&
-                     (int64_t)d->m * d->ldo * 2 < lim && (!d->resid || (int64_t)d->m * d->ldr * 2 < lim);  // (the 320-wide tile's epilogue)
+                     (int64_t)d->m * d->ldo * 2 < lim && (!d->resid || (int64_t)d->m * d->ldr * 2 < lim) &&
+                     // the epilogue's vector table (gemm8.hip): 16-byte loads of bias / LayerNorm vectors / row-add rows, at most
+                     // 5 row-add rows per 256-row tile
+                     ((uintptr_t)d->bias & 15) == 0 && ((uintptr_t)d->ln_rowsum & 15) == 0 && ((uintptr_t)d->ln_bias & 15) == 0 &&
+                     (!d->rowadd || (((uintptr_t)d->rowadd & 15) == 0 && d->ld_rowadd % 8 == 0 && a.rowadd_div >= 64));
   if (tile == 0 && g8_ok && d->m >= 1024 && d->k >= 256) {
     // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
     // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last
@@ -1014,6 +1022,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
             (size_t)d->split_k * d->m * d->n * 4 <= d->workspace_bytes) {
           a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
         }
+      }
+      if (d->chan_sums && a.split_k == 1 && d->act == MVOC_ACT_NONE) {  // statistics of the stored tile from the epilogue
+        a.stats = (float*)d->chan_sums;
+        g_sums_written = 1;
       }
       const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : 320, s);
       if (rc == 0 && a.split_k > 1) {

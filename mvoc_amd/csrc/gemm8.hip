@@ -25,9 +25,13 @@
 //   carry an offset beyond the resource's range -- the hardware range check returns zeros.  No per-issue vector ALU work.
 // * Epilogue: arithmetic in the accumulator layout, fp16 result parked in a wave-private LDS tile, read back as 16-byte row
 //   chunks, residual added, stored (same rounding points as gemm_epilogue_lds).
+#include <type_traits>
+
 #include "gemm_args.h"
 
 namespace {
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // epilogue stores non-temporal: a block's 128 KB output tile leaves in a chip-wide burst while its CU idles (s_endpgm waits for the
 // stores), and nobody re-reads it from this XCD's L2 (the consumer is another kernel, the tensor several times the L2): +7 % at
@@ -36,6 +40,7 @@ namespace {
 #define G8_NT_STORE 1
 #endif
 constexpr unsigned G8_OOB = 0x80000000u;  // >= num_records of every resource: the load returns zeros
+__device__ const uint4 g8_zero16 = {0u, 0u, 0u, 0u};
 
 #define G8_BAR()                         \
   do {                                   \
@@ -43,6 +48,9 @@ constexpr unsigned G8_OOB = 0x80000000u;  // >= num_records of every resource: t
     __builtin_amdgcn_s_barrier();        \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
+
+// n / d for n < 2^31 and a launch constant d as one multiply-high (g8_magic below): exact, see the derivation there
+__device__ __forceinline__ unsigned g8_udiv(unsigned n, unsigned mg, int sh) { return sh < 0 ? n : __umulhi(n, mg) >> sh; }
 
 template <int N>
 __device__ __forceinline__ void g8_wait_vm() {
@@ -88,10 +96,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   constexpr int SMEM = 2 * KB + NY0 * YB;
   constexpr int XPC = XH / 8;            // 1 KB pieces per X half-tile: 16 / 20
   constexpr int PXM = (XPC + 7) / 8;     // per wave, at most
-  static_assert(SMEM <= 163840, "LDS budget");
+  // Epilogue vector table (bias fp16 [BX] | ln_s fp32 [BX] | ln_c fp32 [BX] | row-add fp16 [RA_ROWS][BX]; one 16-byte chunk per
+  // thread, filled by ONE LDS-DMA per wave): behind the ring where the LDS has room (256-wide: requested in the prologue, landed
+  // long before it is read), otherwise inside the dead ring behind the eight waves' epilogue tiles (320-wide: requested after
+  // the K loop).
+  constexpr int PITCH = XQ * 2 + 16;     // epilogue: 144 / 176 B per pixel row of a wave's fp16 tile
+  constexpr int RA_ROWS = 5;             // rowadd_div >= 64 (host check): a 256-row tile touches at most 5 row-add rows
+  constexpr int NB = BX / 8, NL = BX / 4, TOT = NB + 2 * NL + RA_ROWS * NB;  // 16-byte chunks of the table
+  constexpr bool TBL_EARLY = SMEM + 8192 <= 163840;
+  constexpr int T_B = TBL_EARLY ? SMEM : 8 * 64 * PITCH, T_LS = T_B + NB * 16, T_LC = T_LS + NL * 16, T_RA = T_LC + NL * 16;
+  static_assert(TOT <= 512 && T_B + 8192 <= (TBL_EARLY ? SMEM + 8192 : SMEM), "epilogue table");
+  static_assert(SMEM + (TBL_EARLY ? 8192 : 0) <= 163840, "LDS budget");
   static_assert(YP || !UPS, "the upsample form keeps its offsets in registers");
   static_assert(!(AFF && UPS), "an upsampled source is not affine");
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM + (TBL_EARLY ? 8192 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,10 +117,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const int wr = wave >> 2, wc = wave & 3;
   G8_STAMP(0);
   const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
-  const int slice = (int)(logical0 % (unsigned)p.split_k);
-  const unsigned logical = logical0 / (unsigned)p.split_k;
-  const int n0 = (int)(logical % (unsigned)p.n_tiles) * BX;
-  const int m0 = (int)(logical / (unsigned)p.n_tiles) * 256;
+  const unsigned logical = g8_udiv(logical0, p.mg_sk, p.sh_sk);
+  const int slice = (int)(logical0 - logical * (unsigned)p.split_k);
+  const unsigned mtile = g8_udiv(logical, p.mg_nt, p.sh_nt);
+  const int n0 = (int)(logical - mtile * (unsigned)p.n_tiles) * BX;
+  const int m0 = (int)mtile * 256;
   const int kbeg = slice * p.k_per_split;
   const int nk = p.k_per_split / 64;
   // X pieces of this wave per half-tile (wave-uniform): 2, or 3 / 2 for BX = 320
@@ -143,6 +162,29 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   // one and a half K tiles of nothing.  vmcnt arithmetic unchanged: all of tile 0 is still issued before any of tile 1.
   G8_ISSUE_X(0, OX0, xso0); G8_ISSUE_X(1, OX1, xso1);
   __builtin_amdgcn_sched_barrier(0);
+  // chunk `tid` of the epilogue table: absent operands, channels past N / n_store and rows past the tile's last row-add row read
+  // the zero constant (r16(x + 0) == x)
+  const bool t_ln = EPI == 0 ? p.ln_s != nullptr : EPI >= 2;
+  const unsigned ra_row0 = p.rowadd ? g8_udiv((unsigned)m0, p.mg_ra, p.sh_ra) : 0u;
+  auto request_table = [&]() {
+    const void* src = &g8_zero16;
+    if (tid < NB) {
+      const int n = n0 + tid * 8;
+      if (p.bias && !t_ln && n < p.N) src = p.bias + n;
+    } else if (tid < NB + 2 * NL) {
+      const int c = tid - NB, v = c >= NL;
+      const int n = n0 + (c - v * NL) * 4;
+      if (EPI != 1 && t_ln && n < p.N) src = (v ? p.ln_c : p.ln_s) + n;
+    } else if (tid < TOT) {
+      const int c = tid - NB - 2 * NL;
+      const int r = c / NB, n = n0 + (c - r * NB) * 8;
+      const unsigned ra_rows = p.rowadd ? g8_udiv((unsigned)min(m0 + 255, p.M - 1), p.mg_ra, p.sh_ra) - ra_row0 + 1u : 0u;
+      if (EPI != 2 && EPI != 3 && (unsigned)r < ra_rows && n < p.n_store) src = p.rowadd + (size_t)(ra_row0 + r) * p.ld_rowadd + n;
+    }
+    if (wave * 64 < TOT)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, G8_LDS(T_B + wbase), 16, 0, 0);
+  };
+  __builtin_amdgcn_sched_barrier(0);
   // activation side: per staged row a source-row index for tap (0,0) and a mask of the taps inside the image (two 16-bit
   // masks per register)
   int rowoff[AFF ? 1 : 2][AFF ? 1 : 2];
@@ -164,20 +206,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       if constexpr (YP) yoff[h][q] = G8_OOB;
       unsigned mk = live ? 1u : 0u;
       if (p.a_mode == MVOC_A_CONV3X3) {
-        const int hwout = p.hout * p.wout;
-        const int img = mm / hwout;
-        const int rem = mm - img * hwout;
-        const int oy = rem / p.wout;
+        const int img = (int)g8_udiv((unsigned)mm, p.mg_hwout, p.sh_hwout);
+        const int rem = mm - img * (p.hout * p.wout);
+        const int oy = (int)g8_udiv((unsigned)rem, p.mg_wout, p.sh_wout);
         const int y0 = oy * p.stride - p.pad, x0 = (rem - oy * p.wout) * p.stride - p.pad;
         if constexpr (!AFF) rowoff[h][q] = (img * p.hsrc + y0) * p.wsrc + x0;
+        // tap (ky, kx) is inside the image iff row y0 + ky and column x0 + kx are: three column bits, replicated per live row
+        unsigned cb = 0;
         mk = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int iy = y0 + t / 3, ix = x0 + t % 3;
-          if (live && iy >= 0 && ix >= 0 && iy < p.hup && ix < p.wup) mk |= 1u << t;
-        }
+        for (int t = 0; t < 3; ++t) cb |= (unsigned)(x0 + t) < (unsigned)p.wup ? 1u << t : 0u;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) mk |= (unsigned)(y0 + t) < (unsigned)p.hup ? cb << (3 * t) : 0u;
+        if (!live) mk = 0;
       } else if (p.a_mode == MVOC_A_TEMPORAL3) {
-        const int f = (mm / p.hw) % p.frames;
+        const unsigned vf = g8_udiv((unsigned)mm, p.mg_hw, p.sh_hw);  // frame index over all videos
+        const int f = (int)(vf - g8_udiv(vf, p.mg_fr, p.sh_fr) * (unsigned)p.frames);
         mk = 0;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -277,11 +321,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   // XT = 5: the accumulate is pinned IN PLACE by an asm statement (D = C): the register file is full (160 accumulators + 56
   // fragment registers) and hipcc's out-of-place MFMA form cost ~110 v_mov_b64 accumulator copies per two K tiles.  Hazards
   // hipcc no longer sees: an MFMA's D feeding the next MFMA as C needs no wait state; every other reader of an accumulator
-  // (the epilogue) sits behind the loop's last s_barrier; the A / B operands come from LDS reads that hipcc waits for (they are
-  // register inputs of the statement).
+  // (the epilogue) sits behind the loop's last s_barrier AND an explicit s_nop pair; the A / B operands come from LDS reads that
+  // hipcc waits for (they are register inputs of the statement).
   auto mma = [&](f32x4& c, const half8_t& a, const half8_t& b) {
     if constexpr (XT == 5) {
-      asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     } else {
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
@@ -311,6 +355,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   } else {
     g8_wait_vm<0>();
   }
+  // 256-wide: the table is requested HERE, behind the prologue's wait (in front of it the first K tile waited for the table's
+  // cold lines too: + 900 ticks of prologue, phase stamps); every later counted wait retires it -- it is older than the pieces
+  // they leave in flight -- and the epilogue starts with vmcnt(0) + a barrier anyway
+  if constexpr (TBL_EARLY) request_table();
   G8_BAR();
   G8_STAMP(1);
   if (wr == 1) G8_BAR();  // group 1 falls one barrier behind
@@ -376,6 +424,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   } while (0)
 
   int t = 0;
+  // (build.py compiles this file with -falign-loops=64: the loop's time moved by 1.2 % -- 2 446 -> 2 476 ticks per K tile -- with
+  // the placement an unrelated edit of the prologue happened to give its first instruction)
 #pragma unroll 1
   for (; t + 1 < nk; t += 2) {
     G8_KTILE(0, t);
@@ -383,6 +433,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
   if (t < nk) G8_KTILE(0, t);
   if (wr == 0) G8_BAR();  // group 0's balancing barrier: every wave is out of the K loop, the ring is free
+  // XT = 5: hipcc does not know the asm statements above are MFMAs and inserts no MFMA -> VALU wait states; whatever reads an
+  // accumulator first (the slab stores, the epilogue arithmetic) must not depend on what happens to sit in between
+  if constexpr (XT == 5) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   G8_STAMP(2);
 
   const int g = fg;  // lane owns channels nq + 4 g .. + 3 of pixel (lane & 15) per 16 x 16 tile
@@ -404,13 +457,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  // Two passes (a = 0, 1: the wave's two channel halves), each: arithmetic in the accumulator layout -> fp16 tile in a
+  // wave-private LDS region -> read back as 16-byte row chunks, residual added, stored.  One block per CU: every memory round
+  // trip in here is paid with all MFMAs idle, so
+  // * the per-channel vectors of the block (bias, LayerNorm-fold row sums / constants, the time-embedding row-add rows of the
+  //   tile's <= RA_ROWS samples) are fetched ONCE per block into an LDS table (request_table above) and read from LDS where they
+  //   are used (round 3 fetched them per pass into 40-50 registers: two more L2 round trips per block, and no room to issue
+  //   anything else early);
+  // * the residual chunks of BOTH passes are requested before pass 0's arithmetic where the registers allow (256-wide), pass 1's
+  //   at the latest before pass 0's stores: vmcnt retires in issue order, a load issued behind the 8 / 10 stores of pass 0
+  //   waits for their acknowledgement under the chip-wide store burst (phase stamps, 320-wide: pass 1 20 k ticks against 12 k).
   const bool geglu = EPI == 0 ? p.act == MVOC_ACT_GEGLU : EPI == 3;
   const bool use_ln = EPI == 0 ? p.ln_s != nullptr : EPI >= 2;
-  const bool use_bias = p.bias && !use_ln;
-  constexpr int PITCH = XQ * 2 + 16;        // 144 / 176 B per pixel row of the wave's tile
+  constexpr bool GG = XT == 4 && (EPI == 0 || EPI == 3);  // instantiations that carry the GEGLU arithmetic
+  constexpr bool LNF = EPI != 1;                          // ... the LayerNorm-fold arithmetic
+  constexpr bool RADD = EPI != 2 && EPI != 3;             // ... a row-add (the host sends LayerNorm fold + row-add to the general form)
   char* epi = smem + wave * (64 * PITCH);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (!TBL_EARLY) request_table();
+  // pixel row of lane fr in the four (b, j) tiles: LayerNorm statistics, row-add row inside the table
   float ln_mu[2][2], ln_rs[2][2];
-  unsigned raoff[2][2];  // element offset of this lane's row in the row-add tensor
+  int raoff[2][2];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -418,45 +485,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       const int m = m0 + wc * 64 + b * 32 + j * 16 + fr;
       const int ms = m < p.M ? m : p.M - 1;
       ln_mu[b][j] = 0.f; ln_rs[b][j] = 1.f;
-      if (use_ln) { ln_mu[b][j] = p.ln_stats[2 * (size_t)ms]; ln_rs[b][j] = p.ln_stats[2 * (size_t)ms + 1]; }
-      raoff[b][j] = p.rowadd ? (unsigned)(ms / p.rowadd_div) * (unsigned)p.ld_rowadd : 0u;
+      if (LNF && use_ln) { ln_mu[b][j] = p.ln_stats[2 * (size_t)ms]; ln_rs[b][j] = p.ln_stats[2 * (size_t)ms + 1]; }
+      raoff[b][j] = RADD && p.rowadd ? (int)(g8_udiv((unsigned)ms, p.mg_ra, p.sh_ra) - ra_row0) * (BX * 2) : 0;
     }
-  // per-channel / per-row vectors through resources: an absent operand is a zero-sized resource (every load returns zeros)
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(use_bias ? (const void*)p.bias : (const void*)p.w), 0, use_bias ? p.N * 2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ls = __builtin_amdgcn_make_buffer_rsrc((void*)(use_ln ? (const void*)p.ln_s : (const void*)p.w), 0, use_ln ? p.N * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_lc = __builtin_amdgcn_make_buffer_rsrc((void*)(use_ln ? (const void*)p.ln_c : (const void*)p.w), 0, use_ln ? p.N * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.rowadd ? (const void*)p.rowadd : (const void*)p.w), 0, p.rowadd ? 0x7ffffff0 : 0, 0x00020000);
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {  // (fully unrolled: the accumulators must be indexed statically)
-    const int nq = n0 + wr * XH + a * XQ;  // first packed weight row of this pass
-    const int nchunk = geglu ? 4 : XT * 2, nbase = geglu ? nq / 2 : nq;
-    // Every per-channel vector of the pass (bias, LayerNorm-fold row sums / constants, time-embedding row-add) is requested up
-    // front through range-checked buffer loads -- absent operands and columns past n_store read zeros, so there is no branch and
-    // ONE wait.  (As conditional global loads hipcc emitted load -> s_waitcnt vmcnt(0) twenty times per pass, each a full L2
-    // round trip with every MFMA idle.)
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid ? p.resid : p.out), 0, p.resid ? (int)((size_t)p.M * p.ldr * 2) : 0, 0x00020000);
+  const int nchunk = geglu ? 4 : XT * 2;
+  auto nq_of = [&](int a) { return n0 + wr * XH + a * XQ; };  // first packed weight row of pass a
+
+  // arithmetic of pass A in the accumulator layout (same fp16 rounding points as gemm_epilogue_lds), fp16 tile -> LDS
+  auto arith = [&](auto A_) {
+    constexpr int a = decltype(A_)::value;  // (the accumulators must be indexed statically)
+    const int cb = wr * XH + a * XQ + 4 * g;  // this lane's first channel of tile i = 0, relative to n0
     if (geglu) {
-      if constexpr (XT == 4 && (EPI == 0 || EPI == 3)) {
+      if constexpr (GG) {
         // packed rows: blocks of 64 = 32 value rows then 32 gate rows -> tiles i = 0, 1 are values, i + 2 their gates
-        u32x2 bh2[2], bg2[2];
-        u32x4e sh4[2], sg4[2], ch4[2], cg4[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int nh_ = nq + i * 16 + 4 * g;
-          const unsigned ob = nh_ < p.N ? (unsigned)nh_ * 2u : G8_OOB, ol = nh_ < p.N ? (unsigned)nh_ * 4u : G8_OOB;
-          bh2[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ob, 0, 0);
-          bg2[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, ob, 64, 0);
-          sh4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ls, ol, 0, 0);
-          sg4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ls, ol, 128, 0);
-          ch4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lc, ol, 0, 0);
-          cg4[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lc, ol, 128, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const half4_t bh = __builtin_bit_cast(half4_t, bh2[i]), bg = __builtin_bit_cast(half4_t, bg2[i]);
-          const f32x4 sh = __builtin_bit_cast(f32x4, sh4[i]), sg = __builtin_bit_cast(f32x4, sg4[i]);
-          const f32x4 ch = __builtin_bit_cast(f32x4, ch4[i]), cg = __builtin_bit_cast(f32x4, cg4[i]);
+          const int c = cb + i * 16;
+          const half4_t bh = *reinterpret_cast<const half4_t*>(smem + T_B + c * 2), bg = *reinterpret_cast<const half4_t*>(smem + T_B + (c + 32) * 2);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(smem + T_LS + c * 4), sg = *reinterpret_cast<const f32x4*>(smem + T_LS + (c + 32) * 4);
+          const f32x4 ch = *reinterpret_cast<const f32x4*>(smem + T_LC + c * 4), cg = *reinterpret_cast<const f32x4*>(smem + T_LC + (c + 32) * 4);
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -474,101 +524,165 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         }
       }
     } else {
-      u32x2 b2[XT], t2[XT][2][2];
-      u32x4e s4v[XT], c4v[XT];
 #pragma unroll
       for (int i = 0; i < XT; ++i) {
-        const int n = nq + i * 16 + 4 * g;
-        const bool live = n < p.n_store;
-        b2[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, live ? (unsigned)n * 2u : G8_OOB, 0, 0);
-        if (EPI == 0 || EPI == 2) {
-          s4v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ls, live ? (unsigned)n * 4u : G8_OOB, 0, 0);
-          c4v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_lc, live ? (unsigned)n * 4u : G8_OOB, 0, 0);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            t2[i][b][j] = EPI == 2 ? u32x2{0u, 0u}  // (the LayerNorm-fold form carries no row-add: the host sends that pair to the general form)
-                                   : __builtin_amdgcn_raw_buffer_load_b64(rs_ra, live ? (raoff[b][j] + (unsigned)n) * 2u : G8_OOB, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < XT; ++i) {
-        const half4_t b4 = __builtin_bit_cast(half4_t, b2[i]);
+        const int c = cb + i * 16;
+        const half4_t b4 = *reinterpret_cast<const half4_t*>(smem + T_B + c * 2);
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, c4 = s4;
-        if (EPI == 0 || EPI == 2) { s4 = __builtin_bit_cast(f32x4, s4v[i]); c4 = __builtin_bit_cast(f32x4, c4v[i]); }
+        if constexpr (LNF) { s4 = *reinterpret_cast<const f32x4*>(smem + T_LS + c * 4); c4 = *reinterpret_cast<const f32x4*>(smem + T_LC + c * 4); }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            float v[4];
+            float x[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = r16(use_ln ? ln_rs[b][j] * (acc[a][b][i][j][e] - ln_mu[b][j] * s4[e]) + c4[e] : acc[a][b][i][j][e] + (float)b4[e]);
-            const half4_t t4 = __builtin_bit_cast(half4_t, t2[i][b][j]);  // zeros without a row-add: r16(v + 0) == v
+              x[e] = r16(LNF && use_ln ? ln_rs[b][j] * (acc[a][b][i][j][e] - ln_mu[b][j] * s4[e]) + c4[e] : acc[a][b][i][j][e] + (float)b4[e]);
+            if constexpr (RADD) {
+              const half4_t t4 = *reinterpret_cast<const half4_t*>(smem + T_RA + raoff[b][j] + c * 2);  // zeros without a row-add: r16(x + 0) == x
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)t4[e]);
+              for (int e = 0; e < 4; ++e) x[e] = r16(x[e] + (float)t4[e]);
+            }
             if (EPI == 0 && p.act == MVOC_ACT_SILU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = r16(silu_f(v[e]));
+              for (int e = 0; e < 4; ++e) x[e] = r16(silu_f(x[e]));
             } else if (EPI == 0 && p.act == MVOC_ACT_GELU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = r16(gelu_fast_f(v[e]));
+              for (int e = 0; e < 4; ++e) x[e] = r16(gelu_fast_f(x[e]));
             }
             half4_t o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)x[e];
             *reinterpret_cast<half4_t*>(epi + (b * 32 + j * 16 + fr) * PITCH + (i * 16 + 4 * g) * 2) = o;
           }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's tile is in LDS (a wave's DS ops execute in order)
-    if (a == 0) G8_STAMP(6);
-    // Read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row; residual added, stored.
-    // Branch-free through range-checked buffer instructions (rows >= M fall outside the resource, columns >= n_store get an
-    // out-of-range offset): one 32-bit offset per chunk instead of a 64-bit address and an exec mask, so that ALL residual
-    // chunks of the pass are in flight together (two loads in flight per lane left the chip-wide output burst at 2.4 TB/s with
-    // every MFMA idle -- phase stamps: 2 x 22 k ticks per block against 2.3 k per K tile), even beside the other pass's
-    // accumulators of the 320-wide tile.
-    {
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((size_t)p.M * p.ldo * 2), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_r =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid ? p.resid : p.out), 0, p.resid ? (int)((size_t)p.M * p.ldr * 2) : 0, 0x00020000);
-      auto chunk_off = [&](int ln, int it, int ld) -> unsigned {
-        const int idx = ln + 64 * it;
-        const int px = idx / nchunk, c = idx - px * nchunk;
-        const int m = m0 + wc * 64 + px, n = nbase + c * 8;
-        return (it < nchunk && n < p.n_store) ? (unsigned)(m * ld + n) * 2u : G8_OOB;
-      };
-      u32x4 rr[XT * 2];
-      __builtin_amdgcn_sched_barrier(0);  // (not before the pass's accumulators are dead)
+  };
+  // Read back as rows: 16-byte chunks, consecutive lanes on consecutive chunks of a pixel row; residual added, stored.
+  // Branch-free through range-checked buffer instructions (rows >= M fall outside the resource, columns >= n_store get an
+  // out-of-range offset): one 32-bit offset per chunk instead of a 64-bit address and an exec mask, so that ALL residual
+  // chunks of a pass are in flight together (two loads in flight per lane left the chip-wide output burst at 2.4 TB/s with
+  // every MFMA idle -- phase stamps: 2 x 22 k ticks per block against 2.3 k per K tile).
+  auto chunk_off = [&](int a, int ln, int it, int ld) -> unsigned {
+    const int nbase = geglu ? nq_of(a) / 2 : nq_of(a);
+    const int idx = ln + 64 * it;
+    const int px = idx / nchunk, c = idx - px * nchunk;
+    const int m = m0 + wc * 64 + px, n = nbase + c * 8;
+    return (it < nchunk && n < p.n_store) ? (unsigned)(m * ld + n) * 2u : G8_OOB;
+  };
+  auto load_resid = [&](int a, u32x4 (&rr)[XT * 2], int i0, int i1) {
 #pragma unroll
-      for (int it = 0; it < XT * 2; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, chunk_off(lane, it, p.ldr), 0, 0);  // zeros without a residual
-      // (the index arithmetic is redone from an opaque copy of the lane id: shared with the loads above, hipcc keeps four
-      // values per chunk alive across the wait and spills them)
-      int lane2 = lane;
-      asm volatile("" : "+v"(lane2));
+    for (int it = 0; it < XT * 2; ++it)
+      if (it >= i0 && it < i1) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, chunk_off(a, lane, it, p.ldr), 0, 0);  // zeros without a residual
+  };
+  // 320-wide: 160 accumulators are live until pass 0's arithmetic is done, and 7 of pass 1's 10 chunks are what fits beside
+  // pass 0's readback without a spill (8: 2 registers spilled, 10: 12)
+  constexpr int R1_EARLY = 7;
+  auto readback_store = [&](int a, const u32x4 (&rr)[XT * 2]) {
+    // (the index arithmetic is redone from an opaque copy of the lane id: shared with the loads, hipcc keeps four values per
+    // chunk alive across the wait and spills them)
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));
 #pragma unroll
-      for (int it = 0; it < XT * 2; ++it) {
-        const int idx = lane2 + 64 * it;
-        const int px = idx / nchunk, c = idx - px * nchunk;
-        half8_t v = *reinterpret_cast<const half8_t*>(epi + (it < nchunk ? px * PITCH + c * 16 : 0));
-        const half8_t r8 = __builtin_bit_cast(half8_t, rr[it]);
-        if (p.resid) {
+    for (int it = 0; it < XT * 2; ++it) {
+      const int idx = lane2 + 64 * it;
+      const int px = idx / nchunk, c = idx - px * nchunk;
+      half8_t v = *reinterpret_cast<const half8_t*>(epi + (it < nchunk ? px * PITCH + c * 16 : 0));
+      const half8_t r8 = __builtin_bit_cast(half8_t, rr[it]);
+      if (p.resid) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(lane2, it, p.ldo), 0, G8_NT_STORE ? 2 : 0);
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
       }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(a, lane2, it, p.ldo), 0, G8_NT_STORE ? 2 : 0);
+      if (p.stats && it < nchunk) *reinterpret_cast<half8_t*>(epi + px * PITCH + c * 16) = v;  // the STORED values, for stats_pass
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
-    G8_STAMP(3 + a);
+  };
+  // Per-channel sum and sum of squares of the values just stored (what the consumer's GroupNorm reads: pnp_utils.py:909-910,
+  // 953-965, 1048-1051 normalise exactly these tensors), over this wave's 64 pixels, on the idle matrix pipe: with X^T fragments
+  // (channel on the lane, 8 pixels per lane: transposing LDS reads of the tile) as BOTH operands, D = X^T X is the Gram matrix of
+  // a 16-channel block -- its diagonal the sums of squares, fp32-exact products -- and ones x X the column sums.  4 (5) x 2 x 2
+  // MFMAs per pass instead of a separate pass over the tensor (gn_partial: 3.4 % of GPU time in round 3).
+  constexpr int S_OFF = TBL_EARLY ? 8 * 64 * PITCH : T_B + 8192;  // fp32 [wc][BX][2] behind the tiles / the table
+  static_assert(S_OFF + 4 * BX * 8 <= SMEM, "statistics area");
+  auto stats_pass = [&](int a) {
+    const half8_t ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+    const int kg = lane >> 4, n = lane & 15;
+    float* so = reinterpret_cast<float*>(smem + S_OFF) + (wc * BX + wr * XH + a * XQ) * 2;
+#pragma unroll
+    for (int cb = 0; cb < XT; ++cb) {
+      f32x4 dg = {0.f, 0.f, 0.f, 0.f}, dsum = dg;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        // 16-lane group kg: pixels 32 ps + 8 kg + {0..3} and + {4..7}; lane 4 q + pc supplies row q, columns 4 pc .. 4 pc + 3
+        const char* va = epi + (32 * ps + 8 * kg + (n >> 2)) * PITCH + (cb * 16 + 4 * (n & 3)) * 2;
+        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
+        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 4 * PITCH));
+        half8_t f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = (half_t)lo[e]; f[4 + e] = (half_t)hi[e]; }
+        dg = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, f, dg, 0, 0, 0);
+        dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, f, dsum, 0, 0, 0);
+      }
+      // D[m][n] sits in lane (n, m >> 2), register m & 3: the diagonal element of channel n in the lane whose group is n >> 2
+      const float sq = (n & 3) == 0 ? dg[0] : (n & 3) == 1 ? dg[1] : (n & 3) == 2 ? dg[2] : dg[3];
+      if (kg == (n >> 2)) *reinterpret_cast<float2*>(so + (cb * 16 + n) * 2) = float2{dsum[0], sq};
+    }
+  };
+  {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    u32x4 r0[XT * 2], r1[XT * 2];
+    g8_wait_vm<0>();  // the table has landed (256-wide: long ago; this wave's piece -- the barrier makes it every wave's)
+    G8_BAR();
+    if constexpr (XT == 4) { load_resid(0, r0, 0, XT * 2); load_resid(1, r1, 0, XT * 2); }
+    __builtin_amdgcn_sched_barrier(0);
+    arith(I0{});
+    G8_STAMP(6);
+    __builtin_amdgcn_sched_barrier(0);  // (320-wide: 160 live accumulators until here)
+    if constexpr (XT != 4) { load_resid(0, r0, 0, XT * 2); load_resid(1, r1, 0, R1_EARLY); }
+    __builtin_amdgcn_sched_barrier(0);
+    readback_store(0, r0);
+    G8_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (XT != 4) load_resid(1, r1, R1_EARLY, XT * 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.stats) stats_pass(0);
+    __builtin_amdgcn_sched_barrier(0);
+    arith(I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    readback_store(1, r1);
+    G8_STAMP(4);
+    if (p.stats) {
+      stats_pass(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      G8_BAR();
+      // the four pixel quarters of the tile, summed in a fixed order: [m tile][n_store][2] fp32, coalesced
+      for (int i = tid; i < BX * 2; i += 512) {
+        const int ch = i >> 1;
+        if (n0 + ch < p.n_store) {
+          const float* si = reinterpret_cast<const float*>(smem + S_OFF) + i;
+          p.stats[((size_t)(m0 >> 8) * p.n_store + n0) * 2 + i] = ((si[0] + si[BX * 2]) + si[2 * BX * 2]) + si[3 * BX * 2];
+        }
+      }
+    }
   }
 #ifdef MVOC_G8_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G8_STAMP(5);
 #endif
+}
+
+// floor(n / d) == umulhi(n, mg) >> sh for every n < 2^31: with l = ceil(log2 d), P = 31 + l and mg = ceil(2^P / d) (< 2^32 as
+// d > 2^(l-1), = 2^31 for a power of two), the error e = mg d - 2^P lies in [0, d), so n e < 2^31 2^l = 2^P and
+// floor(n mg / 2^P) = floor(n / d) (Granlund & Montgomery); umulhi drops 32 of the P bits, sh = l - 1.
+void g8_magic(unsigned d, unsigned& mg, int& sh) {
+  if (d <= 1) { mg = 0; sh = -1; return; }
+  int l = 0;
+  while ((1ull << l) < d) ++l;
+  mg = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  sh = l - 1;
 }
 
 template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
@@ -578,6 +692,13 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
   constexpr int BX = XT * 64;
   a.n_tiles = (a.N + BX - 1) / BX;
   a.m_tiles = (a.M + 255) / 256;
+  g8_magic((unsigned)a.n_tiles, a.mg_nt, a.sh_nt);
+  g8_magic((unsigned)a.split_k, a.mg_sk, a.sh_sk);
+  g8_magic((unsigned)(a.hout * a.wout), a.mg_hwout, a.sh_hwout);
+  g8_magic((unsigned)a.wout, a.mg_wout, a.sh_wout);
+  g8_magic((unsigned)a.hw, a.mg_hw, a.sh_hw);
+  g8_magic((unsigned)a.frames, a.mg_fr, a.sh_fr);
+  g8_magic((unsigned)a.rowadd_div, a.mg_ra, a.sh_ra);
   const long nblk = (long)a.n_tiles * a.m_tiles * a.split_k;
   if (nblk <= 0 || nblk > 0x7fffffffL) {
     mvoc_set_error("gemm8: grid of %ld blocks", nblk);

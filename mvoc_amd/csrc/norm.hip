@@ -20,6 +20,11 @@ struct GnArgs {
   half_t* out;
   float* ws;  // [nsample][nchunk][G][3] partials, then [nsample][G][2] finals
   float* mom_out;  // when set, gn_final writes the sample's raw (count, mean, M2) here instead of (mean, rstd)
+  // statistics from the producers' epilogues (mvoc_gemm_desc.chan_sums): per 256-row slab and channel {sum, sum of squares} of
+  // the rows of x (x2); gn_partial is skipped and gn_final folds the channels of a group itself
+  const float* sums;
+  const float* sums2;
+  int nslab;       // 256-row slabs per sample
   int nsample, R, c, c1, c2, G, cpg, silu;
   int nchunk, rows_per_chunk;
   int CW, RY, npass;
@@ -119,7 +124,27 @@ __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
   const int gl = tid % GL, lane = tid / GL;
   const int g = blockIdx.y * GL + gl;
   GnMoments acc = {0.f, 0.f, 0.f};
-  if (lane < lanes) {
+  if (p.sums) {
+    if (lane < lanes) {
+      // channels g cpg .. of one source (a group never straddles the two sources: c1 % cpg == 0, checked by the host)
+      const int ch0 = g * p.cpg;
+      const bool second = ch0 >= p.c1;
+      const int cs = second ? p.c2 : p.c1;
+      const float* base = (second ? p.sums2 : p.sums) + ((long)smp * p.nslab * cs + (second ? ch0 - p.c1 : ch0)) * 2;
+      const float n = 256.f * (float)p.cpg;
+      for (int sl = lane; sl < p.nslab; sl += lanes) {
+        const float* in = base + (long)sl * cs * 2;
+        float sx = 0.f, sq = 0.f;
+        for (int c = 0; c < p.cpg; ++c) {
+          const float2 v = *reinterpret_cast<const float2*>(in + 2 * c);
+          sx += v.x;
+          sq += v.y;
+        }
+        const float mean = sx / n;
+        gn_merge(acc, n, mean, fmaxf(sq - sx * mean, 0.f));
+      }
+    }
+  } else if (lane < lanes) {
     const float* base = p.ws + ((long)smp * p.nchunk * p.G + g) * 3;
     for (int c0 = lane; c0 < p.nchunk; c0 += lanes * 8) {
       float nb[8], mb[8], qb[8];
@@ -228,7 +253,10 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
 }
 
 // group-blocks per sample for gn_final: split the groups over 4 blocks when there are few samples and many slabs
-int gn_final_blocks(const GnArgs& a) { return (a.nsample < 16 && a.nchunk > 64 && a.G % 4 == 0 && a.G >= 8) ? 4 : 1; }
+int gn_final_blocks(const GnArgs& a) {
+  const int n = a.sums ? a.nslab : a.nchunk;
+  return (a.nsample < 16 && n > 64 && a.G % 4 == 0 && a.G >= 8) ? 4 : 1;
+}
 
 void gn_geometry(GnArgs& a) {
   const int cchunks = a.c / 8;
@@ -458,7 +486,15 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
   // algorithmic bytes: read x once for stats + once for apply is the implementation; compulsory = read + write
   MvocProfScope prof(MVOC_FAM_GN, s, 2.0 * 2.0 * (double)d->nsample * d->rows_per_sample * d->c);
   dim3 grid(a.nchunk, a.nsample);
-  hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
+  if (d->chan_sums) {
+    MVOC_REQUIRE(d->rows_per_sample % 256 == 0 && (!d->x2 || d->chan_sums2) && a.c1 % a.cpg == 0, -2,
+                 "groupnorm: chan_sums needs rows_per_sample %% 256 == 0, sums of both sources, and groups that do not straddle them");
+    a.sums = (const float*)d->chan_sums;
+    a.sums2 = (const float*)d->chan_sums2;
+    a.nslab = d->rows_per_sample / 256;
+  } else {
+    hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");

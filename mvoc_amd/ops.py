@@ -153,14 +153,20 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     return out
 
 
-def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=64, causal=False, scale=0.0):
+def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=64, causal=False, scale=0.0, v2=None, out2=None):
     """softmax(q k^T * scale) v.  q [nbatch*tq, >=heads*head_dim] / k, v [(nbatch/kv_bdiv)*tk, ..] row-major views.
-    head_dim 64 (scale 1/8) is the UNet's; 96 + an explicit scale + ``causal`` serve the CLIP towers (clip.py)."""
-    _chk(q, "q"), _chk(k, "k"), _chk(v, "v")
+    head_dim 64 (scale 1/8) is the UNet's; 96 + an explicit scale + ``causal`` serve the CLIP towers (clip.py).
+    ``v2`` / ``out2`` (views laid out like ``v`` / ``out``): a second value tensor attending with the same q and k -- the PnP
+    destination pair (include/mvoc_hip.h); the result equals two plain calls bit for bit."""
+    _chk(q, "q"), _chk(k, "k"), _chk(v, "v"), _chk(v2, "v2"), _chk(out2, "out2")
     if out is None:
         out = torch.empty((nbatch * tq, heads * head_dim), dtype=torch.float16, device=q.device)
     d = AttnDesc()
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    if v2 is not None:
+        if out2 is None or _rowmajor(v2, "v2") != _rowmajor(v, "v") or _rowmajor(out2, "out2") != _rowmajor(out, "out"):
+            raise RuntimeError("flash_attn: the paired form needs out2, and v2 / out2 laid out like v / out")
+        d.v2, d.out2 = v2.data_ptr(), out2.data_ptr()
     d.q_ts, d.k_ts, d.v_ts, d.o_ts = _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(v, "v"), _rowmajor(out, "out")
     d.q_bs, d.k_bs, d.v_bs, d.o_bs = tq * d.q_ts, tk * d.k_ts, tk * d.v_ts, tq * d.o_ts
     d.nbatch, d.heads, d.tq, d.tk, d.kv_bdiv = nbatch, heads, tq, tk, kv_bdiv

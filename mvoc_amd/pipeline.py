@@ -428,7 +428,7 @@ class I2VGenXLPipeline:
         # a captured iteration bakes in EVERY site's injecting() decision (the reference allows a schedule per site) and
         # the device copies of the masks: both are part of the variant key
         u = self.unet
-        vkey = (u.injection_flags(), u.mask_key(st["masks"]))
+        vkey = (u.injection_flags(), u.mask_key(st["masks"]), bool(u.pair_destinations), bool(u.prune_dead_chunks))
         g = st["variants"].get(vkey)
         if g is None:
             g = st["variants"][vkey] = GraphedStep(st["body"], preserve=(st["latents"],))

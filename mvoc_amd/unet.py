@@ -258,13 +258,23 @@ class Transformer2DModel(_TransformerBase):
         qkv = blk.attn1.to_qkv.call_ln(h, blk.norm1)
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         proc = blk.attn1.processor
+        ndst = 0
         if proc.injecting() and not eng._pruned:
             ndst = eng.check_pnp_batch(B, proc.mask)
             masks = eng.device_masks(proc.mask)[1]  # bool masks as {0,1} fp16
             ld = qkv.stride(0)
             ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
                                  f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background, ndst=ndst)
-        a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
+        if ndst == 2 and eng.pair_destinations:
+            # the injection has just written ONE blended q / k into both destination chunks (pnp_utils.py:664-668): their
+            # softmax(q k^T) is the same matrix -- computed once, multiplied into the two chunks' own v (bit-identical outputs)
+            a = torch.empty((nimg * hw, c), dtype=H16, device=x.device)
+            ns, rows = (B - 2) * F, F * hw
+            s0, s1, s2 = slice(0, ns * hw), slice(ns * hw, ns * hw + rows), slice(ns * hw + rows, ns * hw + 2 * rows)
+            ops.flash_attn(q[s0], k[s0], v[s0], nbatch=ns, heads=self.heads, tq=hw, tk=hw, out=a[s0])
+            ops.flash_attn(q[s1], k[s1], v[s1], nbatch=F, heads=self.heads, tq=hw, tk=hw, out=a[s1], v2=v[s2], out2=a[s2])
+        else:
+            a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
         h = blk.attn1.to_out(a, resid=h)
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
         q2 = blk.attn2.to_q.call_ln(h, blk.norm2)
@@ -491,6 +501,9 @@ class I2VGenXLUNet:
         # demo's first 5 of 50 composition steps.
         self.prune_dead_chunks = True
         self._pruned = False
+        # Q/K-injection sites: the two destination chunks attend with identical q and k (the hook assigns one blend to both);
+        # their attention probabilities are computed once (ops.flash_attn v2 / out2).  False: five independent passes (A/B, tests)
+        self.pair_destinations = True
 
     def set_frame_shard(self, shard):
         """Frame-shard every forward over the ranks of ``shard`` (``mvoc_amd.frame_shard``): each rank receives the FULL

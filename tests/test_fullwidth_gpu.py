@@ -154,6 +154,13 @@ def test_ext_forward_with_all_hooks_full_width(pair, trio):
         assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD, (t, rel, mx)
         if t == 981:  # conv_out injection: chunks 3 and 4 leave the network identical (SURVEY B-5)
             assert torch.equal(out[3], out[4])
+        else:  # Q/K injection only: one softmax(q k^T) for the destination pair == five independent passes, bit for bit
+            eng.pair_destinations = False
+            try:
+                five = eng.forward_ext(x["sample"], t, x["fps"], x["il1"], x["il"], x["ie"], x["eh"])[0]
+            finally:
+                eng.pair_destinations = True
+            assert torch.equal(out, five)
 
 
 def test_one_inversion_and_one_composition_step_full_width(pair, trio):

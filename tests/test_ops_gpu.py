@@ -485,6 +485,45 @@ def test_flash_attn_large_scores(ops):
     assert (out.float().cpu() - ref).abs().max() < 1e-2
 
 
+def test_flash_attn_deferred_max(ops):
+    """the running maximum is rescaled only when it grew by more than 2^8 (attention.hip: FLASH_THR): keys that lift a row's
+    maximum by LESS than the threshold in late tiles leave P > 1 against the stale maximum -- checked against an fp64 softmax
+    for growth just below, at and above the threshold, in the first and in later tiles"""
+    g = torch.Generator().manual_seed(11)
+    t = 640
+    q = torch.randn(t, 64, generator=g).half()
+    k = (0.25 * torch.randn(t, 64, generator=g)).half()
+    v = torch.randn(t, 64, generator=g).half()
+    n2 = (q[7].float() ** 2).sum()
+    for key, lift in ((3, 2.0), (130, 5.0), (200, 7.5), (330, 8.0), (460, 8.5), (590, 15.0)):  # score = lift / log2(e) in natural units
+        k[key] = (q[7].float() * (lift / 1.4426950408889634 * 8.0 / n2)).half()
+    k[100] = (q[40].float() * (6.0 / 1.4426950408889634 * 8.0 / (q[40].float() ** 2).sum())).half()
+    out = ops.flash_attn(dev(q), dev(k), dev(v), nbatch=1, heads=1, tq=t, tk=t)
+    p64 = torch.softmax(q.double() @ k.double().t() / 8.0, dim=-1)
+    ref = (p64 @ v.double()).float()
+    assert rel_l2(out, ref) < 2e-3
+    assert (out.float().cpu() - ref).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("t,heads,nb", [(256, 2, 3), (1000, 5, 2), (4096, 1, 1)])
+def test_flash_attn_pair_equals_two_calls(ops, t, heads, nb):
+    """PnP destination pair (pnp_utils.py:664-668: one blended q / k for the unconditional and the conditional chunk): the paired
+    launch (v2 / out2) returns, bit for bit, what two plain launches with the same q / k return"""
+    g = torch.Generator().manual_seed(t + heads)
+    c = heads * 64
+    qkv = dev(torch.randn(2 * nb * t, 3 * c, generator=g).half())  # [pair member, batch, token] rows of a fused QKV buffer
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    half = nb * t
+    a = ops.flash_attn(q[:half], k[:half], v[:half], nbatch=nb, heads=heads, tq=t, tk=t)
+    b = ops.flash_attn(q[:half], k[:half], v[half:], nbatch=nb, heads=heads, tq=t, tk=t)
+    out = torch.zeros(2 * half, c, dtype=torch.float16, device=q.device)
+    ops.flash_attn(q[:half], k[:half], v[:half], nbatch=nb, heads=heads, tq=t, tk=t, out=out[:half], v2=v[half:], out2=out[half:])
+    assert torch.equal(out[:half], a) and torch.equal(out[half:], b)
+    q4, k4 = (x[:half].float().cpu().reshape(nb, t, heads, 64).transpose(1, 2) for x in (q, k))
+    v4 = v[half:].float().cpu().reshape(nb, t, heads, 64).transpose(1, 2)
+    assert rel_l2(out[half:], F.scaled_dot_product_attention(q4, k4, v4).transpose(1, 2).reshape(half, c)) < 2e-3
+
+
 @pytest.mark.parametrize("frames,heads", [(16, 2), (3, 1), (32, 1), (8, 5)])
 def test_temporal_attn(ops, frames, heads):
     g = torch.Generator().manual_seed(frames)

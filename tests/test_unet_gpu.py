@@ -85,6 +85,14 @@ def test_g7_pnp_against_reference_golden(golden_dir):
         out = eng.forward_ext(t("sample"), tt, t("fps"), t("image_latents_first"), t("image_latents"),
                               t("image_embeddings"), t("encoder_hidden_states"))[0]
         _close(out, torch.from_numpy(g["pnp_out_" + tag]), "g7 pnp " + tag)
+        if tt == 861:  # Q/K-injection-only step: the destination pair shares one softmax(q k^T) (pair_destinations) -- bit-identical
+            eng.pair_destinations = False  # to five independent attention passes
+            try:
+                five = eng.forward_ext(t("sample"), tt, t("fps"), t("image_latents_first"), t("image_latents"),
+                                       t("image_embeddings"), t("encoder_hidden_states"))[0]
+            finally:
+                eng.pair_destinations = True
+            assert torch.equal(out, five)
         if tt == 981:  # feature-injection steps: chunks 3 and 4 leave conv_out identical (SURVEY B-5)
             assert torch.equal(out[3], out[4])
             # ... and nothing computed FOR them reaches the output: the engine runs such a step on the source chunks only

@@ -26,6 +26,12 @@ for (c, hw) in ((320, 4096), (640, 1024), (1280, 256), (1280, 64)):
     us = timeit(lambda: ops.flash_attn(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], nbatch=nb, heads=heads, tq=hw, tk=hw))
     fl = 4.0 * nb * heads * hw * hw * 64
     print(f"self  nb={nb} heads={heads} T={hw}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
+    if hasattr(ops.AttnDesc, "v2") and nb % 2 == 0:  # the PnP destination pair: one softmax(q k^T), two value tensors
+        half = nb // 2 * hw
+        out = torch.empty(nb * hw, c, device="cuda", dtype=torch.float16)
+        us2 = timeit(lambda: ops.flash_attn(qkv[:half, :c], qkv[:half, c:2 * c], qkv[:half, 2 * c:], nbatch=nb // 2, heads=heads, tq=hw, tk=hw,
+                                            out=out[:half], v2=qkv[half:, 2 * c:], out2=out[half:]))
+        print(f"pair  nb={nb // 2}x2 heads={heads} T={hw}: {us2:8.1f} us  (two plain launches of the same work: {us:8.1f} us)  {fl / us2 / 1e6:7.1f} TF/s equivalent")
     q = torch.randn(nb * hw, c, device="cuda").half()
     kv = torch.randn(B * 145, 2 * c, device="cuda").half()
     us = timeit(lambda: ops.flash_attn(q, kv[:, :c], kv[:, c:], nbatch=nb, heads=heads, tq=hw, tk=145, kv_bdiv=16))
