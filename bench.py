@@ -227,14 +227,14 @@ def roofline_leg(job, steps):
     alg_bytes = [0.0]
     real_gemm = ops._gemm
 
-    def spy(d, dev=None):
+    def spy(d, dev=None, *rest, **kw):
         if d.a_mode == 1:
             a_elems = d.nimg * d.hsrc * d.wsrc * d.cin
         else:
             a_elems = d.m * d.cin
         ns = d.n // 2 if d.act == 1 else (d.n_store if d.n_store > 0 else d.n)
         alg_bytes[0] += 2.0 * (a_elems + d.n * d.k + d.m * ns * (2 if d.resid else 1))
-        return real_gemm(d, dev)
+        return real_gemm(d, dev, *rest, **kw)
 
     real_xs = ops.xs_linear
 
@@ -292,7 +292,7 @@ def roofline_leg(job, steps):
             break
         traffic_note = f"{rel} was taken with another build of the library: not reported"
     return {
-        "bound": "mfma", "kernel": "implicit-GEMM family: gemm8_kernel (eight-phase 256-pixel tiles: 69 % of the family's time) + gemm_glds_kernel / gemm_kernel (the general tiles) for linear / conv3x3 / temporal conv, + xslin_kernel (K = 320 projections)",
+        "bound": "mfma", "kernel": "implicit-GEMM family: gemm8_kernel (eight-phase 256-pixel tiles; its share of the family's time is in the rocprofv3 summary under profiles/) + gemm_glds_kernel / gemm_kernel (the general tiles) for linear / conv3x3 / temporal conv, + xslin_kernel (K = 320 projections)",
         "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4),
         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate rocprofv3 --pmc passes over the same step mix)",
         "traffic_source": traffic_src, "traffic_note": traffic_note,

@@ -66,8 +66,8 @@ typedef struct mvoc_gemm_desc {
   void* workspace;      /* optional fp32 scratch for split-K partial slabs: split_k * m * n * 4 bytes */
   size_t workspace_bytes;
   /* LayerNorm folded into the GEMM (F.layer_norm feeding F.linear at pnp_utils.py:250/296/322 -> :604-612, :335):
-   * `a` holds the RAW rows, `w` holds gamma-scaled weights W' = W * gamma; the kernel accumulates mean / rstd of every
-   * row from the tiles it stages anyway and the epilogue forms rstd*(acc - mean*ln_rowsum[n]) + ln_bias[n].
+   * `a` holds the RAW rows, `w` holds gamma-scaled weights W' = W * gamma; the epilogue forms
+   * rstd*(acc - mean*ln_rowsum[n]) + ln_bias[n] with the rows' {mean, rstd} from `ln_stats` (REQUIRED in this mode).
    * ln_rowsum = sum_k W'[n,k], ln_bias = beta @ W^T + bias, both fp32 [n]; `bias` is ignored in this mode.  NULL = off. */
   const void* ln_rowsum;
   const void* ln_bias;
@@ -75,8 +75,9 @@ typedef struct mvoc_gemm_desc {
   int32_t pad_mode;     /* conv3x3: 0 = zero padding 1 on every side (F.conv2d(padding=1)); 1 = one row / column of zeros at the
                            BOTTOM / RIGHT only (F.pad(x, (0,1,0,1)) + conv2d(padding=0, stride=2): the downsamplers of the VAE
                            encoder, diffusers Downsample2D(padding=0)) */
-  const void* ln_stats; /* optional {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (one read of the rows, shared by
-                           every n-tile); NULL: each block accumulates the statistics of its rows in the K loop */
+  const void* ln_stats; /* {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (two-pass variance, one read of the rows, shared
+                           by every n-tile).  (Until round 4 a NULL here made each block accumulate E[x^2] - mean^2 in its K loop:
+                           the last one-pass variance of the library, removed.) */
   void* chan_sums;      /* optional REQUEST, fp32 [ceil(m / 256)][n_store][2]: per 256-row slab and output channel, the sum and the
                            sum of squares of the values this call stores (fp16-rounded, residual included) -- the first pass of the
                            GroupNorm that reads `out` next (F.group_norm at pnp_utils.py:909-910, 953-965, 1048-1051, 185-188),
@@ -184,6 +185,12 @@ typedef struct mvoc_gn_desc {
   size_t workspace_bytes;
   int32_t nsample, rows_per_sample, c, c1, groups, silu;
   float eps;
+  /* optional: the statistics pass taken from the producers of x (and x2): what mvoc_gemm_f16 wrote into its descriptor's
+   * chan_sums when it stored these rows -- fp32 [nsample * rows_per_sample / 256][c1][2] (and [..][c - c1][2]).  Needs
+   * rows_per_sample % 256 == 0 and c1 % (c / groups) == 0; both sources' sums when x2 is given.  NULL: the statistics are
+   * read from x. */
+  const void* chan_sums;
+  const void* chan_sums2;
 } mvoc_gn_desc;
 size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups);
 int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream);
@@ -200,6 +207,7 @@ int mvoc_groupnorm_apply_moments_f16(const mvoc_gn_desc* d, const void* parts, i
 
 /* per-row {mean, rstd} (fp32 [rows][2]) of a [rows, c] fp16 matrix: the statistics half of F.layer_norm for GEMMs that
  * fold the normalisation into their epilogue (mvoc_gemm_desc.ln_*) */
+/* c % 8 == 0, c <= 2048 (a row lives in one wave's registers: 4 x 16 bytes per lane) */
 int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int32_t c, float eps, void* stream);
 
 /* LayerNorm over the last dim (F.layer_norm at pnp_utils.py:250,296,322), eps 1e-5, affine */

@@ -49,7 +49,7 @@ class TAttnDesc(C.Structure):
 class GnDesc(C.Structure):
     _fields_ = [("x", vp), ("x2", vp), ("gamma", vp), ("beta", vp), ("out", vp), ("workspace", vp),
                 ("workspace_bytes", sz), ("nsample", i32), ("rows_per_sample", i32), ("c", i32), ("c1", i32),
-                ("groups", i32), ("silu", i32), ("eps", f32)]
+                ("groups", i32), ("silu", i32), ("eps", f32), ("chan_sums", vp), ("chan_sums2", vp)]
 
 
 class TFusedDesc(C.Structure):
@@ -75,6 +75,7 @@ SIGNATURES = {
     "mvoc_last_error": (C.c_char_p, []),
     "mvoc_gemm_f16": (i32, [C.POINTER(GemmDesc), vp]),
     "mvoc_gemm_workspace_bytes": (sz, [i64, i64, i64]),
+    "mvoc_gemm_chan_sums_written": (i32, []),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),

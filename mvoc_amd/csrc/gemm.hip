@@ -620,7 +620,6 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
 
   const int nk = p.k_per_split / BKK;
   const int swz = MVOC_SWZ(r);  // tile bases are multiples of 32 rows: the swizzle depends on r only
-  float ln_s1 = 0.f, ln_s2 = 0.f;
   static_assert(BKK != 64 || TM != 1 || WN * WM * 64 == 2 * BM, "in-kernel LayerNorm statistics assume two threads per staged activation row");
   issue(0);
   if (NST == 3 && nk > 1) issue(1);
@@ -643,22 +642,6 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     }
     const char* wl = smem + cur * STAGE + (wn * TN * 32 + r) * ROW;
     const char* al = smem + cur * STAGE + BN * ROW + (wm * TM * 32 + r) * ROW;
-    if (BKK == 64 && WN * WM * 64 == 2 * BM && p.ln_s && !p.ln_stats) {  // wave-uniform: accumulate sum(x), sum(x^2) of the raw rows from the staged tile
-      const int srow = tid >> 1;
-      const char* rp = smem + cur * STAGE + BN * ROW + srow * ROW;
-      const int rsw = (srow >> 1) & 7;
-      const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const half8_t v = *reinterpret_cast<const half8_t*>(rp + (((tid & 1) * 4 + c4) ^ rsw) * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const half2_t v2 = {v[2 * e], v[2 * e + 1]};
-          ln_s1 = __builtin_amdgcn_fdot2(v2, one2, ln_s1, false);
-          ln_s2 = __builtin_amdgcn_fdot2(v2, v2, ln_s2, false);
-        }
-      }
-    }
     if constexpr (PF != 1) {
 #pragma unroll
       for (int s = 0; s < BKK / 16; ++s) {
@@ -731,7 +714,7 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
     return;
   }
   {
-    if (p.epi_lds && !(p.ln_s && !p.ln_stats)) {
+    if (p.epi_lds) {
       __syncthreads();  // every wave is out of the K loop: the staging buffers are free
       const float* st = p.ln_s ? p.ln_stats + 2 * (size_t)m0 : nullptr;
       if (p.act == MVOC_ACT_GEGLU) {
@@ -744,21 +727,6 @@ __global__ __launch_bounds__(WN* WM * 64) void gemm_glds_kernel(const GemmArgs p
   }
   if (p.ln_s && p.ln_stats) {
     gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, p.ln_stats + 2 * (size_t)m0);
-    return;
-  }
-  if (p.ln_s) {
-    ln_s1 += __shfl_xor(ln_s1, 1);
-    ln_s2 += __shfl_xor(ln_s2, 1);
-    const float mu = ln_s1 / (float)p.K;
-    const float var = fmaxf(ln_s2 / (float)p.K - mu * mu, 0.f);
-    __syncthreads();  // every wave is done with the staging buffers: reuse their first bytes for the row statistics
-    float* lnstat = reinterpret_cast<float*>(smem);
-    if ((tid & 1) == 0) {
-      lnstat[2 * (tid >> 1)] = mu;
-      lnstat[2 * (tid >> 1) + 1] = rsqrtf(var + p.ln_eps);
-    }
-    __syncthreads();
-    gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h, lnstat);
     return;
   }
   gemm_epilogue<WN, WM, TN, TM>(p, acc, n0, m0, wn, wm, r, h);
@@ -837,7 +805,10 @@ extern "C" size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
   return (size_t)8 * (size_t)m * (size_t)n * sizeof(float);
 }
 
-namespace { thread_local int g_sums_written = 0; }
+namespace {
+thread_local int g_sums_written = 0;
+const bool g_trace = getenv("MVOC_GEMM_TRACE") != nullptr;  // diagnostics: one line per launch with the dispatch decision
+}
 extern "C" int mvoc_gemm_chan_sums_written(void) { return g_sums_written; }
 
 extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
@@ -897,16 +868,17 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   const bool glds_ok = d->k % 64 == 0 && d->cin % 64 == 0 && d->c1 % 64 == 0 &&
                        (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin);
   if (d->ln_rowsum) {
-    MVOC_REQUIRE(d->ln_bias && glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && d->split_k <= 1 &&
+    MVOC_REQUIRE(d->ln_bias && d->ln_stats && glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && d->split_k <= 1 &&
                      (d->tile == 0 || d->tile >= 11),
-                 -2, "gemm: LayerNorm folding needs the plain single-source direct-to-LDS path (k %% 64 == 0), no split-K");
+                 -2, "gemm: LayerNorm folding needs the rows' statistics (ln_stats, mvoc_row_stats_f16) and the plain single-source "
+                     "direct-to-LDS path (k %% 64 == 0), no split-K");
   }
   int tile = d->tile;
   int model_sk = 0, g8_sk = 0;
   // ---- eight-phase tiles (gemm8.hip): 81 = 256 channels x 256 pixels per block, 82 = 320 x 256 ------------------------------
   const int64_t rows_a = d->a_mode == MVOC_A_CONV3X3 ? (int64_t)d->nimg * d->hsrc * d->wsrc : d->m;
   const int64_t lim = (int64_t)1 << 31;  // 32-bit MUBUF offsets, rows beyond the range read zeros
-  const bool g8_ok = glds_ok && a.epi_lds && !(d->ln_rowsum && !d->ln_stats) && (a.n_store % 8 == 0) &&
+  const bool g8_ok = glds_ok && a.epi_lds && (a.n_store % 8 == 0) &&
                      rows_a * d->lda * 2 < lim && (d->a2 == nullptr || rows_a * d->lda2 * 2 < lim) &&
                      (int64_t)d->n * d->k * 2 < lim &&
                      (int64_t)d->m * d->ldo * 2 < lim && (!d->resid || (int64_t)d->m * d->ldr * 2 < lim) &&
@@ -944,30 +916,29 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     }
   }
   if (tile == 0 && glds_ok) {
-    const bool stats_precomputed = !(d->ln_rowsum && !d->ln_stats);
-    if (d->k <= 640 && d->m > 2048 && stats_precomputed && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {
+    // what the eight-phase tiles do not take: grids that fill less than ~55 % of the chip after quantisation, M < 1024, K < 256
+    if (d->k <= 640 && d->m > 2048 && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {
       // five to ten K steps: the launch is prologue / epilogue bound, not MFMA bound -- K step 32 halves the LDS per
       // block so four (128x128) or three (160x128) blocks share a CU and hide each other's ramps: 10-20 % faster here
       tile = (d->act == MVOC_ACT_GEGLU || d->n % 128 == 0 || d->n > 320 || d->n % 160) ? 61 : 62;
     } else if (d->act == MVOC_ACT_GEGLU) {
-      // measured (tools/gemm_bench.py): 256-row tiles win from 16 K rows up (the K-step-32 ones need precomputed LN statistics)
-      tile = d->m >= 16384 ? (!stats_precomputed ? 15 : d->n % 256 == 0 ? 67 : 65) : 11;
+      tile = 11;
     } else if (d->m <= 2048 && !(d->workspace && d->k >= 2048)) {
       tile = 13;  // few rows and no split-K: many small blocks (latency-bound regime, outside the model below)
     } else {
       // Pick the tile by a wave-quantisation cost model calibrated on MI355X (tools/gemm_bench.py, B = 1 and B = 5 shape
       // sets).  The K loop is bound by the L2 -> LDS fill rate (~70 GB/s per CU), so a tile's chip-wide rate grows with
       // its flop per staged byte: `rate` = TFLOP/s it sustains when the grid fills the chip.  A launch runs in "waves" of
-      // `slots` resident blocks; a partly filled last wave costs 0.3 + 0.7 * fill of a full one (a full one for the 8-wave tiles).
+      // `slots` resident blocks; a partly filled last wave costs 0.3 + 0.7 * fill of a full one.
+      // (Round 4: the 8-wave tiles 14 / 15 / 65 / 66 / 67 and tile 63 left the build -- no row of any profile since the
+      // eight-phase tiles took their launches; profiles/r3/gemm_per_shape_* keep their numbers.)
       static const struct { int tile, bn, bm, slots; float rate; } cand[] = {
-          {12, 160, 128, 512, 950.f}, {11, 128, 128, 512, 890.f}, {64, 160, 256, 512, 1090.f},
-          {66, 320, 256, 256, 1200.f}, {67, 256, 256, 256, 1180.f}};
+          {12, 160, 128, 512, 950.f}, {11, 128, 128, 512, 890.f}, {64, 160, 256, 512, 1090.f}};
       const bool can_split = d->workspace && d->split_k == 0 && !d->ln_rowsum;
       double best = 0;
       for (const auto& c : cand) {
         if (d->n % c.bn) continue;
-        // measured: below 64 K rows the 256-row tiles' tails cost more than the model says, except 256x256 on deep K
-        if (c.bm == 256 && (!stats_precomputed || (d->m < 65536 && !(c.tile == 67 && d->m >= 16384 && (d->k >= 2560 || d->n >= 2560))))) continue;
+        if (c.bm == 256 && d->m < 65536) continue;  // measured: below 64 K rows the 256-row tile's tail costs more than the model says
         const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn);
         int sk = 1;
         if (can_split && blocks < 384 && c.bm == 128)
@@ -975,8 +946,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
         if (sk > 1 && (size_t)sk * d->m * d->n * 4 > d->workspace_bytes) sk = 1;
         const double w = (double)(blocks * sk) / c.slots;
         const double full = (double)(long)w, frac = w - full;
-        // one block per CU (8-wave tiles): a partial wave costs a full one; two per CU: the survivors run faster alone
-        const double waves = full + (frac > 0 ? (c.slots == 256 ? 1.0 : 0.3 + 0.7 * frac) : 0.0);
+        const double waves = full + (frac > 0 ? 0.3 + 0.7 * frac : 0.0);
         double cost = waves * c.slots * 2.0 * c.bm * c.bn * (double)(d->k / sk) / (c.rate * 1e6);  // us
         if (sk > 1) cost += 5.0 + 2.0 * sk * (double)d->m * d->n * 4.0 / 3.0e6;                    // fp32 slabs + reduce pass
         if (tile == 0 || cost < best) { best = cost; tile = c.tile; model_sk = sk; }
@@ -993,8 +963,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   if (tile >= 11 && d->act != MVOC_ACT_GEGLU && d->workspace && d->split_k != 1 && !d->ln_rowsum) {
     // split-K when the tile grid cannot fill the chip: slices of >= 512 deep, fp32 slabs in the caller's workspace
     const bool t8 = tile == 81 || tile == 82;
-    const int bm = t8 || tile == 14 || tile == 64 || tile == 66 || tile == 67 || tile % 10 == 5 ? 256 : 128;
-    const int bn = tile == 66 || tile == 82 ? 320 : (tile == 67 || tile == 81) ? 256 : (tile % 10 == 2 || tile == 14 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
+    const int bm = t8 || tile == 64 ? 256 : 128;
+    const int bn = tile == 82 ? 320 : tile == 81 ? 256 : (tile % 10 == 2 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
     const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn);
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (model_sk > 0) {
@@ -1007,6 +977,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       a.k_per_split = (int)(d->k / sk);
       a.ws = (float*)d->workspace;
     }
+  }
+  if (g_trace) {
+    fprintf(stderr, "[mvoc gemm] mode %d m %ld n %ld k %ld cin %d act %d resid %d ln %d -> tile %d split_k %d\n", d->a_mode, (long)d->m,
+            (long)d->n, (long)d->k, d->cin, d->act, d->resid != nullptr, d->ln_rowsum != nullptr, tile, (tile == 81 || tile == 82) ? (d->tile ? d->split_k : (g8_sk > 1 ? g8_sk : 1)) : a.split_k);
   }
   {
     if (tile == 81 || tile == 82) {
@@ -1036,14 +1010,13 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       return rc;
     }
   }
-  if (glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && !d->upsample && !(d->ln_rowsum && !d->ln_stats)) {
+  if (glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && !d->upsample) {
     switch (tile) {  // the tiles the selection above produces, in their single-source plain-linear form
       case 11: return launch_glds<2, 2, 2, 2, 2, 0, 64, 1>(a, s);
       case 12: if (d->act != MVOC_ACT_GEGLU) return launch_glds<1, 4, 5, 1, 2, 0, 64, 1>(a, s); break;
       case 13: return launch_glds<1, 4, 2, 1, 2, 0, 64, 1>(a, s);
       case 61: return launch_glds<2, 2, 2, 2, 2, 0, 32, 1>(a, s);
       case 62: if (d->act != MVOC_ACT_GEGLU) return launch_glds<1, 4, 5, 1, 2, 0, 32, 1>(a, s); break;
-      case 65: return launch_glds<1, 4, 4, 2, 2, 0, 32, 1>(a, s);
       default: break;
     }
   }
@@ -1066,39 +1039,17 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     case 13:
       MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
       return launch_glds<1, 4, 2, 1>(a, s);  // 64 x 128
-    case 14:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 14 needs k, cin, c1 %% 64 == 0 and no GEGLU");
-      return launch_glds<1, 8, 5, 1>(a, s);  // 160 x 256, 8 waves
-    case 15:
-      MVOC_REQUIRE(glds_ok, -2, "gemm: glds tiles need k, cin, c1 %% 64 == 0");
-      return launch_glds<2, 4, 2, 2>(a, s);  // 128 x 256, 8 waves
     // K step 32: half the LDS per block -> more resident blocks per CU
     case 61:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 61 needs k, cin, c1 %% 64 == 0 and row statistics");
+      MVOC_REQUIRE(glds_ok, -2, "gemm: tile 61 needs k, cin, c1 %% 64 == 0");
       return launch_glds<2, 2, 2, 2, 2, 0, 32>(a, s);
     case 62:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
-                   "gemm: tile 62 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 62 needs k, cin, c1 %% 64 == 0, no GEGLU");
       return launch_glds<1, 4, 5, 1, 2, 0, 32>(a, s);
-    case 63:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 63 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<1, 4, 2, 1, 2, 0, 32>(a, s);
-    // 64-row-per-wave register tiles (fewer LDS reads per MFMA), K step 32 so that two blocks still fit a CU
+    // 64-row-per-wave register tile (fewer LDS reads per MFMA), K step 32 so that two blocks still fit a CU
     case 64:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
-                   "gemm: tile 64 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
+      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU, -2, "gemm: tile 64 needs k, cin, c1 %% 64 == 0, no GEGLU");
       return launch_glds<1, 4, 5, 2, 2, 0, 32>(a, s);  // 160 x 256
-    case 65:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 65 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<1, 4, 4, 2, 2, 0, 32>(a, s);  // 128 x 256
-    // 8 waves, 64-row-per-wave register tiles: the highest flop per L2 byte (the K loop is bound by the L2 -> LDS fill rate)
-    case 66:
-      MVOC_REQUIRE(glds_ok && d->act != MVOC_ACT_GEGLU && !(d->ln_rowsum && !d->ln_stats), -2,
-                   "gemm: tile 66 needs k, cin, c1 %% 64 == 0, no GEGLU, row statistics");
-      return launch_glds<2, 4, 5, 2, 2, 0, 64>(a, s);  // 320 x 256, K step 64: one 147 KB block per CU (2-5 % over K step 32)
-    case 67:
-      MVOC_REQUIRE(glds_ok && !(d->ln_rowsum && !d->ln_stats), -2, "gemm: tile 67 needs k, cin, c1 %% 64 == 0 and row statistics");
-      return launch_glds<2, 4, 4, 2, 2, 0, 64>(a, s);  // 256 x 256, K step 64 (128 KB)
     default: mvoc_set_error("gemm: unknown tile %d", tile); return -1;
   }
 }

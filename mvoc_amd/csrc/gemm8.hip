@@ -167,6 +167,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const bool t_ln = EPI == 0 ? p.ln_s != nullptr : EPI >= 2;
   const unsigned ra_row0 = p.rowadd ? g8_udiv((unsigned)m0, p.mg_ra, p.sh_ra) : 0u;
   auto request_table = [&]() {
+    // (the two LayerNorm vectors' base pointers pinned in scalar registers: selecting between the kernel arguments per lane, hipcc
+    // fetched the chosen POINTER from the kernarg segment with a vector load and waited vmcnt(0) for it -- behind the LDS-DMA of
+    // K tile 1 in flight)
+    unsigned long long a_ls = (unsigned long long)p.ln_s, a_lc = (unsigned long long)p.ln_c;
+    asm volatile("" : "+s"(a_ls), "+s"(a_lc));
     const void* src = &g8_zero16;
     if (tid < NB) {
       const int n = n0 + tid * 8;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     } else if (tid < NB + 2 * NL) {
       const int c = tid - NB, v = c >= NL;
       const int n = n0 + (c - v * NL) * 4;
-      if (EPI != 1 && t_ln && n < p.N) src = (v ? p.ln_c : p.ln_s) + n;
+      if (EPI != 1 && t_ln && n < p.N) src = reinterpret_cast<const float*>(v ? a_lc : a_ls) + n;
     } else if (tid < TOT) {
       const int c = tid - NB - 2 * NL;
       const int r = c / NB, n = n0 + (c - r * NB) * 8;
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   };
   // 320-wide: 160 accumulators are live until pass 0's arithmetic is done, and 7 of pass 1's 10 chunks are what fits beside
   // pass 0's readback without a spill (8: 2 registers spilled, 10: 12)
-  constexpr int R1_EARLY = 7;
+  constexpr int R1_EARLY = EPI == 2 ? 5 : 7;  // (the LayerNorm-fold form also holds the rows' statistics)
   auto readback_store = [&](int a, const u32x4 (&rr)[XT * 2]) {
     // (the index arithmetic is redone from an opaque copy of the lane id: shared with the loads, hipcc keeps four values per
     // chunk alive across the wait and spills them)

@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict
   if (row >= rows) return;
   const int nch = c / 8;
   const half_t* xr = x + row * c;
-  // two passes (mean, then squared deviations) like F.layer_norm; rows of up to 2048 channels stay in registers (c <= 2048 is
-  // checked by the host), wider ones are re-read from L2
+  // two passes (mean, then squared deviations) like F.layer_norm over the row held in registers: 4 x 16 bytes per lane, i.e.
+  // c <= 2048 -- checked by the host, there is no wider form (include/mvoc_hip.h states the limit)
   half8_t v[4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll

@@ -4,6 +4,7 @@ PyTorch supplies device memory and the current HIP stream; every computation is 
 All activations are fp16, channels-last 2-D ``[rows, C]`` tensors (rows = B*F*H*W).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -41,14 +42,29 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
-def _gemm(d: GemmDesc, dev=None):
+def _gemm(d: GemmDesc, dev=None, out=None, sums=False):
     # problems with few output tiles and a deep K get a scratch for deterministic split-K (see gemm.hip)
     if dev is not None and d.act != ACT_GEGLU and d.split_k != 1:
         nbytes = lib.mvoc_gemm_workspace_bytes(d.m, d.n, d.k)
         if nbytes:
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    cs = None
+    if sums and out is not None and d.m % 256 == 0 and d.act == ACT_NONE and out.is_contiguous():
+        # REQUEST for the producer-epilogue GroupNorm statistics (include/mvoc_hip.h: chan_sums); honoured by the eight-phase tiles
+        cs = torch.empty((d.m // 256, out.shape[1], 2), dtype=torch.float32, device=out.device)
+        d.chan_sums = cs.data_ptr()
     check(lib.mvoc_gemm_f16(C.byref(d), _stream()), "gemm")
+    if cs is not None and lib.mvoc_gemm_chan_sums_written():
+        out.chan_sums = cs  # rides on the tensor OBJECT: a view / slice / copy of it carries no statistics
+
+
+def chan_sums_of(x, rows_per_sample):
+    """the producer's per-slab channel sums of the rows in ``x`` if the GEMM that wrote it emitted them and they fit the norm"""
+    cs = getattr(x, "chan_sums", None)
+    if cs is None or rows_per_sample % 256 or cs.shape[0] * 256 != x.shape[0] or cs.shape[1] != x.shape[1]:
+        return None
+    return cs
 
 
 def _fill_common(d, x, x2, w, out, bias, rowadd, rowadd_div, resid, act, n_store, tile):
@@ -74,7 +90,7 @@ def _out_cols(w, n_store, act):
 
 
 def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0,
-           split_k=0, ln=None):
+           split_k=0, ln=None, sums=False):
     """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T).
     ``ln=(rowsum fp32 [n], lnbias fp32 [n], eps)``: LayerNorm(x) folded into the GEMM (w must be gamma-scaled)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
@@ -98,14 +114,14 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
         rowsum, lnbias, eps = ln[:3]
         _chk(rowsum, "ln rowsum", torch.float32), _chk(lnbias, "ln bias", torch.float32)
         d.ln_rowsum, d.ln_bias, d.ln_eps, d.split_k = rowsum.data_ptr(), lnbias.data_ptr(), eps, 1
-        if len(ln) > 3 and ln[3] is not None:
-            d.ln_stats = _chk(ln[3], "ln stats", torch.float32).data_ptr()
-    _gemm(d, x.device)
+        stats = ln[3] if len(ln) > 3 and ln[3] is not None else row_stats(x, eps)  # (the library has no in-kernel statistics any more)
+        d.ln_stats = _chk(stats, "ln stats", torch.float32).data_ptr()
+    _gemm(d, x.device, out, sums)
     return out
 
 
 def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
-            n_store=0, out=None, tile=0, split_k=0, pad_mode=0):
+            n_store=0, out=None, tile=0, split_k=0, pad_mode=0, sums=False):
     """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
     ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D).
     ``pad_mode=1``: zeros at the bottom / right only (``F.pad(x, (0,1,0,1))`` + ``conv2d(padding=0)``: VAE downsamplers)."""
@@ -131,11 +147,11 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
     d.hup, d.wup = hup, wup
     d.split_k = split_k
     d.pad_mode = pad_mode
-    _gemm(d, x.device)
+    _gemm(d, x.device, out, sums)
     return out, ho, wo
 
 
-def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_k=0):
+def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_k=0, sums=False):
     """Conv3d (3,1,1), pad (1,0,0), on x [nvid*frames*hw, C]; w [N, 3*C] tap-major."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(resid, "resid")
     _rowmajor(x, "x")
@@ -149,7 +165,7 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     d.c1 = d.cin = x.shape[1]
     d.frames, d.hw = frames, hw
     d.split_k = split_k
-    _gemm(d, x.device)
+    _gemm(d, x.device, out, sums)
     return out
 
 
@@ -252,12 +268,21 @@ def _gn_desc(x, gamma, beta, x2, out, nsample, rows_per_sample, groups, eps, sil
     return d, ws
 
 
+USE_CHAN_SUMS = os.environ.get("MVOC_CHAN_SUMS", "1") != "0"  # MVOC_CHAN_SUMS=0: every GroupNorm reads its own statistics (A/B)
+
+
 def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2=None, out=None):
-    """GroupNorm over ``rows_per_sample`` rows x (C/groups) channels per sample, optional fused SiLU; [x | x2] concat."""
+    """GroupNorm over ``rows_per_sample`` rows x (C/groups) channels per sample, optional fused SiLU; [x | x2] concat.
+    When the GEMMs that produced x (and x2) left their per-slab channel sums on the tensors (``_gemm``), the statistics pass
+    over the input is skipped."""
+    c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if out is None:
-        c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
         out = torch.empty((nsample * rows_per_sample, c), dtype=torch.float16, device=x.device)
     d, ws = _gn_desc(x, gamma, beta, x2, out, nsample, rows_per_sample, groups, eps, silu)
+    cs = chan_sums_of(x, rows_per_sample) if USE_CHAN_SUMS else None
+    cs2 = chan_sums_of(x2, rows_per_sample) if (x2 is not None and cs is not None) else None
+    if cs is not None and (x2 is None or cs2 is not None) and x.shape[1] % (c // groups) == 0:
+        d.chan_sums, d.chan_sums2 = cs.data_ptr(), _ptr(cs2)
     check(lib.mvoc_groupnorm_f16(C.byref(d), _stream()), "groupnorm")
     return out
 

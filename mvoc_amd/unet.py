@@ -154,12 +154,13 @@ class Linear:
 
     use_xs = os.environ.get("MVOC_XS", "1") != "0"  # MVOC_XS=0: A/B against the tiled GEMM (diagnostics)
 
-    def __call__(self, x, **kw):
+    def __call__(self, x, sums=False, **kw):
+        """``sums``: ask the GEMM for the GroupNorm statistics of its output (ops._gemm; the activation-stationary kernel has none)"""
         if self._xs_ok(x, kw):
             if self.wp is None:
                 self.wp = pack_xs_weights(self.w, self.b)
             return ops.xs_linear(x, self.wp, self.w.shape[0], n_store=self.n, **kw)
-        return ops.linear(x, self.w, self.b, n_store=self.n, **kw)
+        return ops.linear(x, self.w, self.b, n_store=self.n, sums=sums, **kw)
 
     def fold_layernorm(self, gamma, beta, eps=1e-5):
         """LayerNorm(x) @ W^T + b  ==  rstd * (x @ (W*gamma)^T - mean * rowsum(W*gamma)) + (beta @ W^T + b): the GEMM
@@ -288,7 +289,7 @@ class Transformer2DModel(_TransformerBase):
         h = blk.attn2.to_out(a, resid=h)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
-        return self.proj_out(h, resid=x)
+        return self.proj_out(h, resid=x, sums=True)  # (the next module opens with a GroupNorm of this tensor)
 
 
 class TransformerTemporalModel(_TransformerBase):
@@ -336,7 +337,7 @@ class TransformerTemporalModel(_TransformerBase):
             h = attn.to_out(a, resid=h)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
-        return self.proj_out(h, resid=x)
+        return self.proj_out(h, resid=x, sums=True)  # (the next module opens with a GroupNorm of this tensor)
 
 
 class ResnetBlock2D(Hookable):
@@ -369,19 +370,20 @@ class ResnetBlock2D(Hookable):
         else:
             tproj = self.time_emb_proj(temb_act)  # [B, Cout]; identical for all frames of a sample
         h, _, _ = ops.conv3x3(h, self.conv1_w, self.conv1_b, nimg=nimg, h=H, wd=W, rowadd=tproj, rowadd_div=F * hw,
-                              n_store=self.cout)
+                              n_store=self.cout, sums=True)  # norm2's statistics from this conv's epilogue
         h = ops.groupnorm(h, *self.norm2, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-5, silu=True)
         if self.injecting() and not eng._pruned:
             h, _, _ = ops.conv3x3(h, self.conv2_w, self.conv2_b, nimg=nimg, h=H, wd=W, n_store=self.cout)
             eng.inject_features(h, self.mask, geo, self.cout)
             if self.conv_shortcut is not None:
-                return self.conv_shortcut(x, x2=skip, resid=h)
+                return self.conv_shortcut(x, x2=skip, resid=h, sums=True)
             return ops.add(x, h)
         if self.conv_shortcut is not None:
             sc = self.conv_shortcut(x, x2=skip)
         else:
             sc = x
-        out, _, _ = ops.conv3x3(h, self.conv2_w, self.conv2_b, nimg=nimg, h=H, wd=W, resid=sc, n_store=self.cout)
+        out, _, _ = ops.conv3x3(h, self.conv2_w, self.conv2_b, nimg=nimg, h=H, wd=W, resid=sc, n_store=self.cout,
+                                sums=True)  # the temporal conv stack that follows opens with a GroupNorm
         return out
 
 
@@ -406,7 +408,7 @@ class TemporalConvLayer(Hookable):
         h = x
         for i, (norm, w, b) in enumerate(self.stages):
             h = eng.groupnorm5d(h, norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-5, silu=True)
-            h = ops.tconv3(h, w, b, nvid=B, frames=F, hw=hw, resid=x if i == 3 else None)
+            h = ops.tconv3(h, w, b, nvid=B, frames=F, hw=hw, resid=x if i == 3 else None, sums=True)
         if self.injecting() and not eng._pruned:
             eng.inject_features(h, self.mask, geo, h.shape[1], full_hw=full_hw)
         return h
@@ -420,7 +422,7 @@ class Upsample2D:
     def forward(self, x, geo, size=None):
         B, F, H, W = geo
         up = size if size is not None else (2 * H, 2 * W)
-        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, upsample_to=tuple(up), n_store=self.b.shape[0])
+        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, upsample_to=tuple(up), n_store=self.b.shape[0], sums=True)
         return out, (B, F, ho, wo)
 
 
@@ -431,7 +433,7 @@ class Downsample2D:
 
     def forward(self, x, geo):
         B, F, H, W = geo
-        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, stride=2, n_store=self.b.shape[0])
+        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, stride=2, n_store=self.b.shape[0], sums=True)
         return out, (B, F, ho, wo)
 
 
@@ -713,6 +715,8 @@ class I2VGenXLUNet:
         ld = h.stride(0)
         ops.pnp_blend_tokens(h, hard, frames=F, height=H, width=W, channels=channels, chunk_stride=F * H * W * ld,
                              f_stride=H * W * ld, p_stride=ld, base_chunk0=True, ndst=ndst)
+        if getattr(h, "chan_sums", None) is not None:
+            h.chan_sums = None  # rewritten in place: the producer's GroupNorm statistics no longer describe these rows
 
     # ---- frame-axis shard plumbing --------------------------------------------------------------------
     def temporal_section(self, x, geo, section):

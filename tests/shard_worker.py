@@ -198,6 +198,51 @@ def rccl_native(out_dir):
               open(os.path.join(out_dir, f"rccl_r{rank}.json"), "w"))
 
 
+def rccl_native_multi(out_dir):
+    """the NATIVE transport across real GPUs (one rank per device): every rank builds the same seeded full tensor, so the result
+    of each exchange is known by slicing -- peer order, per-peer byte counts and the all-to-all / all-gather signatures are
+    verified against it for both exchange forms, then a frame-sharded forward against the unsharded one.  Only reachable on a
+    box with >= 2 GPUs (tests/test_frame_shard_gpu.py skips otherwise)."""
+    from mvoc_amd.unet import I2VGenXLUNet
+    from mvoc_amd.unet_spec import UNetConfig
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}"
+    torch.cuda.set_device(dev)
+    rep = {"rank": rank, "world": world}
+    B, F, HW, C = 2, 4 * world, 6 * world, 16
+    g = torch.Generator().manual_seed(7)
+    full = torch.randn(B, F, HW, C, generator=g).half().to(dev)
+    fl, pl = F // world, HW // world
+    mine_f = full[:, rank * fl:(rank + 1) * fl].reshape(-1, C).contiguous()                 # this rank's frames, all pixels
+    mine_p = full[:, :, rank * pl:(rank + 1) * pl].reshape(-1, C).contiguous()              # all frames, this rank's pixels
+    for ex in ("a2a", "allgather"):
+        with FrameShard(exchange=ex, transport="rccl", device=dev) as sh:
+            px = sh.to_pixel_shard(mine_f, B, fl, HW)
+            back = sh.to_frame_shard(px, B, fl, HW)
+            parts = sh.all_gather(mine_f)
+            torch.cuda.synchronize()
+            want_parts = torch.stack([full[:, r * fl:(r + 1) * fl].reshape(-1, C) for r in range(world)])
+            rep[ex] = {"pixel_shard": bool(torch.equal(px, mine_p)), "frame_shard": bool(torch.equal(back, mine_f)),
+                       "all_gather": bool(torch.equal(parts, want_parts))}
+    cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=2, norm_num_groups=8, cross_attention_dim=64,
+                     attention_head_dim=64, transformer_in_heads=2, context_pool=8)
+    eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
+    eng.prune_dead_chunks = False
+    r = lambda *s_: torch.randn(*s_, generator=g).half().to(dev)
+    nf = 2 * world
+    inp = (r(1, 4, nf, 16, 16), torch.tensor([500.0]).to(dev), torch.full((1,), 8.0).to(dev), r(1, 4, nf, 16, 16), r(1, 4, nf, 16, 16),
+           r(1, nf, 64), r(1, 7, 64))
+    ref = eng.forward_ext(*inp)[0]
+    with FrameShard(transport="rccl", device=dev) as sh:
+        eng.set_frame_shard(sh)
+        got = eng.forward_ext(*inp)[0]
+        eng.set_frame_shard(None)
+        torch.cuda.synchronize()
+    rep["forward"] = {"rel_l2": float((got.float() - ref.float()).norm() / ref.float().norm()),
+                      "max_abs": float((got.float() - ref.float()).abs().max()), "ref_max": float(ref.float().abs().max())}
+    json.dump(rep, open(os.path.join(out_dir, f"rccl2_r{rank}.json"), "w"))
+
+
 if __name__ == "__main__":
     mode, out_dir = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
@@ -208,6 +253,8 @@ if __name__ == "__main__":
             pipeline(out_dir)
         elif mode == "rccl":
             rccl_native(out_dir)
+        elif mode == "rccl2":
+            rccl_native_multi(out_dir)
         else:
             unet(out_dir, sys.argv[3] if len(sys.argv) > 3 else "tiny")
         dist.barrier()

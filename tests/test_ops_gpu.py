@@ -35,7 +35,7 @@ def bits(t):
 
 
 # ---- GEMM family -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 61, 62, 64, 81, 82])
 @pytest.mark.parametrize("m", [128, 333, 2048])
 def test_linear_exact_integers(ops, tile, m):
     """integer-valued operands: every product and partial sum is exact, so the MFMA operand / accumulator lane
@@ -121,7 +121,7 @@ def test_linear_layernorm_fold(ops, c, n, geglu):
     assert lin.ln is not None
     assert rel_l2(out, ref) < 2e-3
     assert (out.float().cpu() - ref).abs().max() < 3e-2 * ref.abs().max()
-    # the in-kernel statistics path (no precomputed stats) must agree
+    # without precomputed statistics ops.linear takes them itself (mvoc_row_stats_f16): same result
     out2 = ops.linear(dev(x), lin.w_ln, None, n_store=lin.n, ln=lin.ln, act=ops.ACT_GEGLU if geglu else ops.ACT_NONE)
     assert rel_l2(out2, out) < 1e-3
 
@@ -252,7 +252,7 @@ def test_tconv3(ops, frames, tile):
 # time-embedding row add and the residual.  Operands are small integers: every product and every fp32 partial sum is
 # exact and |result| < 2048 is exact in fp16, so the comparison with torch's CPU conv is BIT-EXACT -- any indexing slip in
 # a tile (tap order, source switch, swizzle, tail rows) shows as a wrong integer.
-PROD_TILES = [0, 11, 12, 13, 14, 15, 61, 62, 63, 64, 65, 66, 67, 81, 82]
+PROD_TILES = [0, 11, 12, 13, 61, 62, 64, 81, 82]  # (round 4 pruned 14, 15, 63, 65, 66, 67: no profile row used them)
 _prod_cache = {}
 
 
@@ -380,7 +380,7 @@ def test_g8_readback_ragged_rows_and_column_views(ops, m, n, ns, k, tile):
     assert bool((untouched == 7.0).all()), "the epilogue wrote outside the output slice"
 
 
-@pytest.mark.parametrize("tile", [0, 11, 15, 61, 65, 67, 81])
+@pytest.mark.parametrize("tile", [0, 11, 61, 81])
 @pytest.mark.parametrize("m,c,inner", [(16384, 320, 1280), (4096, 1280, 5120)])
 def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
     """GEGLU feed-forward entry with the LayerNorm folded in, at C = 320 (L0) and C = 1280 (L2) and production rows, on the
@@ -783,6 +783,38 @@ def test_groupnorm_concat(ops):
     out = ops.groupnorm(dev(x1.reshape(-1, c1)), dev(gm), dev(bt), x2=dev(x2.reshape(-1, c2)), nsample=ns, rows_per_sample=rows,
                         groups=groups, eps=1e-5, silu=True)
     assert rel_l2(out.reshape(ns, rows, c1 + c2), ref) < 2e-3
+
+
+@pytest.mark.parametrize("m,n,k,resid,tile", [(2048, 320, 640, True, 82), (2048, 640, 320 * 2, True, 81), (1024, 1280, 1280, False, 81),
+                                              (4096, 320, 960, True, 81), (2560, 640, 640, False, 82)])
+def test_gemm_chan_sums_and_groupnorm_from_them(ops, m, n, k, resid, tile):
+    """GroupNorm statistics from the producer's epilogue (gemm8.hip: stats_pass): the per-slab channel sums equal the sums of the
+    STORED fp16 values (fp32 accumulation: 1e-5), and a GroupNorm fed with them returns what the three-pass GroupNorm returns
+    on the same tensor, to the accumulation-order noise of its statistics"""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = dev((torch.randn(m, k, generator=g) * 0.7).half())
+    w = dev((torch.randn(n, k, generator=g) / k ** 0.5).half())
+    b = dev(torch.randn(n, generator=g).half())
+    r = dev((torch.randn(m, n, generator=g) * 2 + 1).half()) if resid else None
+    out = ops.linear(x, w, b, resid=r, tile=tile, split_k=1, sums=True)
+    cs = getattr(out, "chan_sums", None)
+    assert cs is not None and tuple(cs.shape) == (m // 256, n, 2)
+    o = out.float().reshape(m // 256, 256, n)
+    assert torch.allclose(cs[..., 0], o.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(cs[..., 1], (o * o).sum(1), rtol=1e-5, atol=1e-3)
+    plain = ops.linear(x, w, b, resid=r, tile=tile, split_k=1)
+    assert torch.equal(plain, out) and getattr(plain, "chan_sums", None) is None
+    gm, bt = dev((1 + 0.2 * torch.randn(n, generator=g)).half()), dev((0.2 * torch.randn(n, generator=g)).half())
+    for rows in (256, m // 2, m):  # 4-D-like samples of one slab each, two samples, one 5-D-like sample
+        y_s = ops.groupnorm(out, gm, bt, nsample=m // rows, rows_per_sample=rows, groups=32, eps=1e-5, silu=True)
+        y_p = ops.groupnorm(plain, gm, bt, nsample=m // rows, rows_per_sample=rows, groups=32, eps=1e-5, silu=True)
+        assert (y_s.float() - y_p.float()).abs().max() <= 4e-3 and rel_l2(y_s, y_p) < 1e-4
+    # a two-source norm (decoder concat) takes both producers' sums
+    out2 = ops.linear(x, w, b, tile=tile, split_k=1, sums=True)
+    gm2, bt2 = torch.cat([gm, gm]), torch.cat([bt, bt])
+    y_s = ops.groupnorm(out, gm2, bt2, x2=out2, nsample=m // 256, rows_per_sample=256, groups=32, eps=1e-5, silu=False)
+    y_p = ops.groupnorm(plain, gm2, bt2, x2=out2.clone(), nsample=m // 256, rows_per_sample=256, groups=32, eps=1e-5, silu=False)
+    assert rel_l2(y_s, y_p) < 1e-4
 
 
 @pytest.mark.parametrize("c", [64, 320, 512, 1280])
