@@ -159,16 +159,10 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
           for (int e = 0; e < 16; ++e) ot[v][dt][e] *= alpha;
     }
     const float mc = mrun * p.scale_log2;
-    float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][e], p.scale_log2, -mc));
-        st[t][e] = pv;
-        ps += pv;
-      }
-    lrun += ps;
+      for (int e = 0; e < 16; ++e) st[t][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][e], p.scale_log2, -mc));
 
     // O^T += V^T P^T : accumulator registers 8s..8s+7 of tile t are the column operand of k-step (t, s)
 #pragma unroll
@@ -178,6 +172,11 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
         half8_t pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (half_t)st[t][8 * s + j];
+        // row sum from the fp16-rounded probabilities that enter P V (numerator and denominator see the same values): one
+        // v_dot2_f32_f16 per pair, fp32 accumulation -- 16 instructions per tile where the fp32 adds were 32 (the kernel is bound
+        // by its vector-instruction issue, not by the matrix pipe)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lrun = __builtin_amdgcn_fdot2(half2_t{pf[2 * j], pf[2 * j + 1]}, half2_t{(half_t)1.f, (half_t)1.f}, lrun, false);
         // V^T fragment by the hardware transpose read: each 16-lane group fetches a block of 4 keys x 16 d of the
         // row-major image (lane 4q+p supplies row q, columns 4p..4p+3) and lane i receives column i of the 4 rows.  The
         // accumulator's k order is two runs of 4 consecutive keys (32t + 16s + 4h + {0..3} and + 8): two reads.

@@ -66,13 +66,14 @@ __device__ __forceinline__ void g8_wait_vm() {
 // AFF: the source row of a staged pixel is affine in its index (plain, temporal, and 3x3 stride-1 same-size convs:
 //   row = m + (ky - 1) W + (kx - 1), validity in the tap masks): ONE row register serves the four staged rows of a lane.
 #ifdef MVOC_G8_STAMPS  // diagnostic build (tools/lab): s_memtime at the phase boundaries of block 0, waves 0 and 4
-__device__ unsigned long long g8_dbg[16];
+__device__ unsigned long long g8_dbg[32];  // [0, 16): s_memtime (shader clock) stamps; [16, 32): s_memrealtime (100 MHz) beside them
 #define G8_STAMP(i)                                                                                   \
   do {                                                                                                \
     if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) {                                   \
-      unsigned long long t_;                                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      unsigned long long t_, r_;                                                                      \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory"); \
       g8_dbg[(wave >> 2) * 8 + (i)] = t_;                                                             \
+      g8_dbg[16 + (wave >> 2) * 8 + (i)] = r_;                                                        \
     }                                                                                                 \
   } while (0)
 #else
@@ -740,7 +741,7 @@ int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
 }
 
 #ifdef MVOC_G8_STAMPS
-extern "C" int mvoc_g8_stamps_read(unsigned long long* host16) {
-  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g8_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+extern "C" int mvoc_g8_stamps_read(unsigned long long* host32) {
+  return hipMemcpyFromSymbol(host32, HIP_SYMBOL(g8_dbg), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -25,6 +25,7 @@ struct GnArgs {
   const float* sums;
   const float* sums2;
   int nslab;       // 256-row slabs per sample
+  int inline_final;  // gn_apply finalises from the sums itself (few slabs, groups divide 256): no gn_final launch
   int nsample, R, c, c1, c2, G, cpg, silu;
   int nchunk, rows_per_chunk;
   int CW, RY, npass;
@@ -112,6 +113,36 @@ __device__ __forceinline__ void gn_merge(GnMoments& a, float nb, float mb, float
   a.n = nt;
 }
 
+// one (slab, group) of the producers' channel sums -> (n, mean, M2): channels g cpg .. of one source (a group never straddles
+// the two sources: c1 % cpg == 0, checked by the host)
+__device__ __forceinline__ void gn_fold_slab(const GnArgs& p, int smp, int g, int sl, float& n, float& mean, float& m2) {
+  const int ch0 = g * p.cpg;
+  const bool second = ch0 >= p.c1;
+  const int cs = second ? p.c2 : p.c1;
+  const float* in = (second ? p.sums2 : p.sums) + (((long)smp * p.nslab + sl) * cs + (second ? ch0 - p.c1 : ch0)) * 2;
+  float sx = 0.f, sq = 0.f;
+  int c = 0;
+  if ((p.cpg & 1) == 0) {
+    // two channels per 16-byte load (even cpg: the group's run starts 16-byte aligned), five loads in flight: as a rolled loop
+    // of dependent 8-byte loads this fold was a chain of cpg L2 round trips per slab (gn_final 6 -> 9 us)
+    for (; c + 10 <= p.cpg; c += 10) {
+      float4 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) v[u] = *reinterpret_cast<const float4*>(in + 2 * c + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) { sx += v[u].x; sq += v[u].y; sx += v[u].z; sq += v[u].w; }
+    }
+  }
+  for (; c < p.cpg; ++c) {
+    const float2 v = *reinterpret_cast<const float2*>(in + 2 * c);
+    sx += v.x;
+    sq += v.y;
+  }
+  n = 256.f * (float)p.cpg;
+  mean = sx / n;
+  m2 = fmaxf(sq - sx * mean, 0.f);
+}
+
 __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
   __shared__ float ln[1024], lmean[1024], lm2[1024];
   // grid (nsample, gridDim.y): block y merges groups [y*GL, (y+1)*GL).  With few samples (the 5-D norms of a B = 1 step:
@@ -126,22 +157,10 @@ __global__ __launch_bounds__(1024) void gn_final(const GnArgs p) {
   GnMoments acc = {0.f, 0.f, 0.f};
   if (p.sums) {
     if (lane < lanes) {
-      // channels g cpg .. of one source (a group never straddles the two sources: c1 % cpg == 0, checked by the host)
-      const int ch0 = g * p.cpg;
-      const bool second = ch0 >= p.c1;
-      const int cs = second ? p.c2 : p.c1;
-      const float* base = (second ? p.sums2 : p.sums) + ((long)smp * p.nslab * cs + (second ? ch0 - p.c1 : ch0)) * 2;
-      const float n = 256.f * (float)p.cpg;
       for (int sl = lane; sl < p.nslab; sl += lanes) {
-        const float* in = base + (long)sl * cs * 2;
-        float sx = 0.f, sq = 0.f;
-        for (int c = 0; c < p.cpg; ++c) {
-          const float2 v = *reinterpret_cast<const float2*>(in + 2 * c);
-          sx += v.x;
-          sq += v.y;
-        }
-        const float mean = sx / n;
-        gn_merge(acc, n, mean, fmaxf(sq - sx * mean, 0.f));
+        float n, mean, m2;
+        gn_fold_slab(p, smp, g, sl, n, mean, m2);
+        gn_merge(acc, n, mean, m2);
       }
     }
   } else if (lane < lanes) {
@@ -207,6 +226,30 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
   const int r1 = min(r0 + p.rows_per_chunk, p.R);
   const long rowbase = (long)smp * p.R;
   const float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + (long)smp * p.G * 2;
+  __shared__ float lfin[2 * 256 + 3 * 256];
+  if (p.inline_final) {
+    // few slabs per sample (the 4-D norms: 16 / 4 / 1): every block finalises its sample's statistics itself from the
+    // producers' channel sums -- ~20 L2 loads per thread against a gn_final launch (6-9 us at B = 1).  Same arithmetic in every
+    // block of the sample: identical statistics.  Thread t folds slabs (t / G) + k (256 / G) of group t % G, G threads merge.
+    const int g = tid % p.G, part = tid / p.G, parts = 256 / p.G;
+    GnMoments acc = {0.f, 0.f, 0.f};
+    for (int sl = part; sl < p.nslab; sl += parts) {
+      float n, mean, m2;
+      gn_fold_slab(p, smp, g, sl, n, mean, m2);
+      gn_merge(acc, n, mean, m2);
+    }
+    float* lm = lfin + 2 * 256;
+    lm[tid * 3] = acc.n; lm[tid * 3 + 1] = acc.mean; lm[tid * 3 + 2] = acc.m2;
+    __syncthreads();
+    if (tid < p.G) {
+      GnMoments t = {0.f, 0.f, 0.f};
+      for (int k = 0; k < parts; ++k) gn_merge(t, lm[(k * p.G + tid) * 3], lm[(k * p.G + tid) * 3 + 1], lm[(k * p.G + tid) * 3 + 2]);
+      lfin[tid * 2] = t.mean;
+      lfin[tid * 2 + 1] = rsqrtf(t.m2 / t.n + p.eps);
+    }
+    __syncthreads();
+    fin = lfin;
+  }
   if (ry >= p.RY) return;
   for (int pass = 0; pass < p.npass; ++pass) {
     const int cc = pass * p.CW + cx;
@@ -492,10 +535,11 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
     a.sums = (const float*)d->chan_sums;
     a.sums2 = (const float*)d->chan_sums2;
     a.nslab = d->rows_per_sample / 256;
+    a.inline_final = a.nslab <= 16 && 256 % a.G == 0;
   } else {
     hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
   }
-  hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
+  if (!a.inline_final) hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");
 }

@@ -50,12 +50,19 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, 0));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  unsigned long long t[16];
+  unsigned long long t[32];
   if (mvoc_g8_stamps_read(t)) { fprintf(stderr, "no stamps\n"); return 1; }
   const int bx = tile == 82 ? 320 : 256;
   const long blocks = (long)((M + 255) / 256) * ((N + bx - 1) / bx);
   printf("M=%d N=%d K=%d tile %d resid %d form %d: %.1f us per launch, %.0f TF/s, %ld blocks = %.2f rounds, %d K tiles\n", M, N, K, tile, use_r, form,
          ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) * 1e-12, blocks, blocks / 256.0, K / 64);
+  {  // the clock the chip held during the K loop of block 0: shader cycles per 100 MHz reference tick
+    const double clk = (double)(t[2] - t[1]) / (double)(t[16 + 2] - t[16 + 1]) * 0.1;
+    const int bxw = tile == 82 ? 320 : 256;
+    const double slots = (double)(K / 64) * 4 * (bxw / 16) * 16 * 2;  // K tiles x phases x MFMAs per wave-phase x 16 cycles x 2 waves per SIMD
+    printf("  K loop: held clock %.3f GHz; MFMA slots filled %.1f %%; every slot filled at this clock = %.0f TFLOP/s on the chip (2 500 nominal at 2.4 GHz)\n",
+           clk, 100.0 * slots / (double)(t[2] - t[1]), 2.0 * 256 * bxw * 64 / (4.0 * (bxw / 16) * 16 * 2) * 256 * clk * 1e-3);
+  }
   for (int g = 0; g < 2; ++g) {
     const unsigned long long* s = t + 8 * g;
     printf("  group %d (ticks): prologue %llu | K loop %llu (%.0f per tile) | epilogue pass 0 %llu (arithmetic + LDS write %llu, readback + stores %llu) | pass 1 %llu | store drain %llu | block %llu\n", g,

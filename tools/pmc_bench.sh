@@ -23,12 +23,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     marks = [i for i, r in enumerate(rows) if "delay_kernel" in r["Kernel_Name"]]
     assert len(marks) >= 2, f"{c}: marker kernels not found ({len(marks)})"
     tot, n = 0.0, 0
+    per = {}
     for r in rows[marks[-2] + 1:marks[-1]]:
-        if "splitk_reduce" in r["Kernel_Name"]:      # second kernel of a split-K call: its bytes belong to that call
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if "splitk_reduce" in name:      # second kernel of a split-K call: its bytes belong to that call
             tot += float(r["Counter_Value"])
-        elif "gemm" in r["Kernel_Name"] or "xslin_kernel" in r["Kernel_Name"]:  # one row per mvoc_gemm_f16 / mvoc_xs_linear_f16 call = one "launch" of bench.py's roofline leg
+        elif "gemm" in name or "xslin_kernel" in name:  # one row per mvoc_gemm_f16 / mvoc_xs_linear_f16 call = one "launch" of bench.py's roofline leg
             tot += float(r["Counter_Value"]); n += 1
-    res[c] = {"sum_kb": tot, "launches": n}
+        else:
+            continue
+        e = per.setdefault(name.split("(")[0], [0, 0.0])
+        e[0] += 1; e[1] += float(r["Counter_Value"])
+    res[c] = {"sum_kb": tot, "launches": n, "per": per}
 fetch = res["FETCH_SIZE"]["sum_kb"] * 1024 * 2   # gfx950: FETCH_SIZE reports half of a wide coalesced read stream
 write = res["WRITE_SIZE"]["sum_kb"] * 1024
 n = res["FETCH_SIZE"]["launches"]
@@ -41,6 +47,10 @@ j = {"kernel": "implicit-GEMM family (gemm8_kernel / gemm_glds_kernel / gemm_ker
      "steps": steps, "mix": "3 inversion : 1 composition", "launches": n, "launches_per_step": n / steps,
      "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n, "hbm_bytes_per_launch": (fetch + write) / n,
      "lib_digest": digest,
+     # which instantiations carry the traffic: launches and corrected bytes per launch of every kernel of the family
+     "by_kernel": {k: {"launches": v[0], "fetch_bytes_per_launch": round(v[1] * 2048 / v[0]),
+                       "write_bytes_per_launch": round(res["WRITE_SIZE"]["per"].get(k, [1, 0.0])[1] * 1024 / max(res["WRITE_SIZE"]["per"].get(k, [1, 0.0])[0], 1))}
+                   for k, v in sorted(res["FETCH_SIZE"]["per"].items(), key=lambda kv: -kv[1][1])},
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --pmc-pass` (the timed step mix, eager "
              "launches, rows between the two marker kernels only); FETCH_SIZE x2 per the gfx950 correction; KB -> bytes x1024"}
 json.dump(j, open(f"{out}/traffic.json", "w"), indent=1)
