@@ -59,6 +59,9 @@ def parse():
                          "BASELINE configs[3]: ONE 32-frame 768x768 clip, frame axis sharded over the GPUs (strong scaling); "
                          "demo = diagnostic: END-TO-END wall-clock of the boat_surf-shaped job through the drop-in drivers "
                          "(3 x inverse.py + composite.py, VAE / CLIP / file IO included; tools/demo_job.py)")
+    ap.add_argument("--sequential-inversions", action="store_true",
+                    help="the job's three source inversions one step after the other on one stream (the definition of rounds 1-3; "
+                         "the default runs the three clips' batch-1 steps concurrently on three streams and reports this form beside it)")
     ap.add_argument("--batch-inversions", action="store_true",
                     help="diagnostic: the 3 source inversions of the job share one UNet call per step (batch 3, "
                          "I2VGenXLPipeline.invert_many) instead of three calls at batch 1; --steps must be a multiple of 4")
@@ -97,6 +100,7 @@ class Job:
         self.inv_table, self.inv_index = self.inv_sched.coef_table(dev, 1.0)
         self.inv_i = 0
         self.batch_inversions = False
+        self.concurrent = False
         self.inv3_state = None
         # ---- composition stream (composite.py on the boat_surf entry of group_composite/group_config.json) -----
         self.sched = DDIMScheduler()
@@ -153,6 +157,47 @@ class Job:
         self.inv3_state = pipe._make_stock_step("bench-inv3", lat, cond, 1.0)
         self.batch_inversions = True
 
+    def enable_concurrent_inversions(self):
+        """the job's three source inversions (bg, obj1, obj2) as three batch-1 loops running AT THE SAME TIME on three HIP
+        streams (I2VGenXLPipeline.invert_concurrent; `inverse.py --concurrent_entries 3`, the driver's default): every clip
+        replays its own captured iteration -- the launches, latents and files of the one-by-one form, bit for bit -- while the
+        other clips' kernels take the CUs a batch-1 launch leaves idle"""
+        pipe = self.pipe
+        saved, pipe._guidance_scale = pipe._guidance_scale, 1.0
+        saved_sched, pipe.scheduler = pipe.scheduler, self.inv_sched
+        self.inv_states = [self.inv_state]
+        for j in (1, 2):
+            cond = pipe._stock_conditioning("", "", f"source-{j}", self.F, self.h * 8, self.w * 8, 8, None, None, None, None)
+            self.inv_states.append(pipe._make_stock_step(f"bench-inv-{j}", self.inv_latents.flip(1 + j), cond, 1.0))
+        pipe._guidance_scale, pipe.scheduler = saved, saved_sched
+        self.inv_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        self.concurrent = True
+
+    def concurrent_inversion_step(self, j):
+        """one step of clip j on its own stream (the three clips of a mix period share the period's timestep)"""
+        if self._hooks_live:
+            from mvoc_amd import pnp_utils
+            pnp_utils.register_time_all(self.pipe, None, None)
+            self._hooks_live = False
+        if j == 0:
+            cur = torch.cuda.current_stream()
+            for s_ in self.inv_streams:  # the period's inversions start behind the previous composition step
+                s_.wait_stream(cur)
+        t = int(self.inv_sched.timesteps[(self.inv_i // 3) % 50])
+        self.inv_i += 1
+        st = self.inv_states[j]
+        with torch.cuda.stream(self.inv_streams[j]):
+            st["t"].fill_(float(t))
+            st["coef"].copy_(self.inv_table[self.inv_index[t]])
+            st["run"]()
+            snap = st["latents"].clone()  # the per-step snapshot invert() hands to the latent cache
+        return snap
+
+    def join_inversions(self):
+        cur = torch.cuda.current_stream()
+        for s_ in self.inv_streams:
+            cur.wait_stream(s_)
+
     def inversion_step(self):
         if self.batch_inversions:
             return self.batched_inversion_step()
@@ -203,7 +248,11 @@ class Job:
 
     def step(self, k):
         if self.is_comp(k):
+            if self.concurrent:
+                self.join_inversions()  # (a job composes after its inversions; nothing of the two stages overlaps here)
             self.composition_step()
+        elif self.concurrent and self.mix == "job":
+            self.concurrent_inversion_step(k % 4)
         elif not self.batch_inversions:
             self.inversion_step()
         elif k % 4 == 0:  # steps k, k+1, k+2 of the mix are the three sources' inversion steps: one batched call
@@ -519,6 +568,10 @@ def main():
             raise SystemExit("--batch-inversions needs --mix job and --steps % 4 == 0 (one batched call = 3 inversion steps)")
         job.enable_batched_inversions()
         args.no_roofline = True  # the roofline leg brackets the metric's own (unbatched) steps
+    concurrent = (not args.sequential_inversions and not args.batch_inversions and not args.no_graphs and args.mix == "job"
+                  and args.steps % 4 == 0)
+    if concurrent:
+        job.enable_concurrent_inversions()
     # prime every graph variant the timed region will replay, then W untimed warm-up steps
     for k in range(4):
         job.step(k)
@@ -526,25 +579,38 @@ def main():
         job.comp_i = j
         job.composition_step()
     job.comp_i = 0
-    for k in range(args.warmup):
-        job.step(k)
-    job.inv_i, job.comp_i = 0, 0
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        job.step(k)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_region():
+        for k in range(args.warmup):
+            job.step(k)
+        if job.concurrent:
+            job.join_inversions()
+        job.inv_i, job.comp_i = 0, 0
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            job.step(k)
+        if job.concurrent:
+            job.join_inversions()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt_], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
+    dt = timed_region()
+    dt_seq = None
+    if concurrent:  # the same K steps in the rounds 1-3 form (one inversion step after the other), reported beside the metric
+        job.concurrent = False
+        dt_seq = timed_region()
+        job.concurrent = True
 
     # per-kind timing (informational), same graphs
     def timed(fn, n):
@@ -555,7 +621,16 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - a) / n * 1e3
 
+    was_concurrent, job.concurrent = job.concurrent, False
     inv_ms = timed(job.inversion_step, 3)
+    inv_conc_ms = None
+    if was_concurrent:
+        def period():
+            for j in range(3):
+                job.concurrent_inversion_step(j)
+            job.join_inversions()
+        job.inv_i = 0
+        inv_conc_ms = timed(period, 3) / 3
     job.comp_i = 0
     comp_ms = timed(job.composition_step, 2)       # Q/K-injection-only steps: 45 of the job's 50
     job.comp_i = 19
@@ -575,6 +650,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {
                 "workload": ("[--batch-inversions: the 3 inversion steps of each mix period run as ONE UNet call at batch 3] " if args.batch_inversions else "") +
+                            ("[the 3 inversion steps of a mix period are one step of each of the job's three source clips (bg, obj1, obj2): "
+                             "independent batch-1 loops run on three HIP streams at the same time -- same launches, bit-identical latents, as "
+                             "one after the other; `sequential_inversions` below is that form] " if was_concurrent else "") +
                             f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "
                             f"(UNet batch 5 = bg+2 objects+uncond+cond, cfg 9.0; the demo's schedule: Q/K injection on every step, "
                             f"resnet / temporal-conv / conv_out feature injection on 5 of 50 -- every tenth composition step of the run; "
@@ -587,11 +665,16 @@ def main():
                 "hip_graphs": not args.no_graphs,
                 "loop_invariant_conditioning": "context tokens, cross-attention K/V of them and the image-latent stem are computed once "
                                                "per loop (I2VGenXLUNet.prepare_conditioning), bit-identical to recomputing them per step",
-                "inversion_step_ms": round(inv_ms, 3), "composition_step_ms": round(comp_ms, 3),
+                "inversion_step_ms": round(inv_ms, 3),
+                "inversion_step_ms_three_clips_concurrent": None if inv_conc_ms is None else round(inv_conc_ms, 3),
+                "sequential_inversions": None if dt_seq is None else {
+                    "value": round(world * args.steps / dt_seq, 4), "ms_per_step": round(dt_seq / args.steps * 1e3, 3),
+                    "note": "the same K steps with the three inversion steps of a period one after the other on one stream (rounds 1-3)"},
+                "composition_step_ms": round(comp_ms, 3),
                 "composition_feature_injection_step_ms": round(compf_ms, 3),
                 "timed_composition_steps": {"qk_injection_only": sum(1 for j in range(sum(1 for k in range(args.steps) if job.is_comp(k))) if j % 10 != 9),
                                             "feature_injection": sum(1 for j in range(sum(1 for k in range(args.steps) if job.is_comp(k))) if j % 10 == 9)},
-                "job_average_ms_per_step": round((150 * inv_ms + 45 * comp_ms + 5 * compf_ms) / 200, 3),
+                "job_average_ms_per_step": round((150 * (inv_conc_ms if inv_conc_ms is not None else inv_ms) + 45 * comp_ms + 5 * compf_ms) / 200, 3),
                 "tflop_per_inversion_step": round(f1 / 1e12, 2), "tflop_per_composition_step": round(f5 / 1e12, 2),
                 "end_to_end_tflops": round(sum(f1 if not job.is_comp(k) else (f3 if (sum(1 for q in range(k) if job.is_comp(q)) % 10 == 9) else f5)
                                                for k in range(args.steps)) / dt / 1e12, 2),
@@ -600,6 +683,7 @@ def main():
     # the two extra legs must never cost the metric line: a failure is reported in place of the object
     if rank == 0 and not args.no_roofline:
         try:
+            job.concurrent = False  # (per-launch HIP-event brackets: one stream, one launch at a time)
             out["roofline"] = roofline_leg(job, args.steps)
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}

@@ -66,9 +66,11 @@ def build_pipeline(device, synthetic):
     return pipe
 
 
-def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch):
+def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch, concurrent=False):
     """--batch_entries N: invert up to N pending clips of identical shape / step count in one batched loop
-    (``I2VGenXLPipeline.invert_many``) before the per-entry pass below, which then finds their latents on disk"""
+    (``I2VGenXLPipeline.invert_many``) before the per-entry pass below, which then finds their latents on disk.
+    --concurrent_entries N (``concurrent``): the same grouping, but every clip keeps its own batch-1 loop and the N loops run at
+    the same time on N HIP streams (``I2VGenXLPipeline.invert_concurrent``): files bit-identical to the one-by-one pass."""
     pending = []
     for entry in configs_list:
         if not entry["active"]:
@@ -94,13 +96,14 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
         inv0 = group[0][1]
         lat = [pipe.encode_vae_video(fl, device=pipe._execution_device, height=inv0.image_size[1], width=inv0.image_size[0])
                for _, _, _, fl in group]
-        logger.info(f"batched inversion of {len(group)} clips: {[g_[1].output_dir for g_ in group]}")
-        pipe.invert_many([g_[1].prompt for g_ in group], [g_[2] for g_ in group], lat, [g_[1].output_dir for g_ in group],
-                         height=inv0.image_size[1], width=inv0.image_size[0], target_fps=inv0.target_fps, num_frames=inv0.n_frames,
-                         num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt)
+        logger.info(f"{'concurrent' if concurrent else 'batched'} inversion of {len(group)} clips: {[g_[1].output_dir for g_ in group]}")
+        run = pipe.invert_concurrent if concurrent else pipe.invert_many
+        run([g_[1].prompt for g_ in group], [g_[2] for g_ in group], lat, [g_[1].output_dir for g_ in group],
+            height=inv0.image_size[1], width=inv0.image_size[0], target_fps=inv0.target_fps, num_frames=inv0.n_frames,
+            num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt)
 
 
-def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1):
+def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1, concurrent_entries=1):
     pipe = build_pipeline(device, synthetic)
     if frame_shard is not None:
         pipe.enable_frame_shard(frame_shard)
@@ -109,6 +112,8 @@ def main(template_config, configs_list, device, synthetic=False, frame_shard=Non
     ddim_scheduler = DDIMScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
     if batch_entries > 1:
         batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch_entries)
+    elif concurrent_entries > 1 and frame_shard is None:
+        batched_inversions(pipe, inverse_scheduler, template_config, configs_list, concurrent_entries, concurrent=True)
     for entry in configs_list:
         if not entry["active"]:
             logger.info(f"Skipping config_entry: {entry}")
@@ -160,6 +165,9 @@ if __name__ == "__main__":
                          "(RCCL; for clips too long for one GPU's latency budget) instead of one entry per rank")
     ap.add_argument("--batch_entries", type=int, default=1,
                     help="invert up to N clips of identical shape in one batched UNet loop (one GPU, cfg 1.0 inversions)")
+    ap.add_argument("--concurrent_entries", type=int, default=3,
+                    help="invert up to N pending clips of identical shape at the same time, each in its own batch-1 loop on its own "
+                         "HIP stream (same launches per clip as the one-by-one pass, bit-identical files; 1 = one by one)")
     args = ap.parse_args()
     template_config = OmegaConf.load(args.template_config)
     logging.basicConfig(level=logging.DEBUG if template_config.debug else logging.INFO,
@@ -179,4 +187,5 @@ if __name__ == "__main__":
         dist.barrier()
         dist.destroy_process_group()
     else:
-        main(template_config, my_entries(configs_list, args.shard), device, args.synthetic, batch_entries=args.batch_entries)
+        main(template_config, my_entries(configs_list, args.shard), device, args.synthetic, batch_entries=args.batch_entries,
+             concurrent_entries=args.concurrent_entries)

@@ -223,6 +223,7 @@ struct TAttnArgs {
   half_t* out;
   long q_bs, q_ps, q_ts, k_bs, k_ps, k_ts, v_bs, v_ps, v_ts, o_bs, o_ps, o_ts;
   int nsample, hw, heads, frames;
+  int logf, logp, pgroups;  // frames == 1 << logf and 1 << logp pixels per 32-row tile when frames is 8 / 16 (else logp = 0); pixel groups per sample
   long ntask;
   float scale_log2;
 };
@@ -234,26 +235,34 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   char* Vs = smem + wave * 64 * TVPITCH;
+  // A 32-row tile holds 32 / F whole sequences when F is 8 or 16 (logp = log2 of the pixels per tile, set by the host; 0
+  // otherwise): row r = (pixel r >> logf, frame r & (F - 1)), a row attends only to the rows of its own pixel -- every lane loads
+  // and stores useful bytes (with one 16-frame sequence per tile half of each load instruction was masked off and the kernel
+  // moved 3.2-3.5 TB/s).
+  const int F = p.frames, logf = p.logf, P = 1 << p.logp;
   const long task = (long)blockIdx.x * 4 + wave;
   const bool active = task < p.ntask;  // whole wave uniform
   const long tk = active ? task : p.ntask - 1;
   const int head = (int)(tk % p.heads);
   const long bp = tk / p.heads;
-  const long smp = bp / p.hw, px = bp % p.hw;
-  const int F = p.frames;
+  const long smp = bp / p.pgroups, px0 = (bp % p.pgroups) << p.logp;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (row -> pixel, frame) of a tile row; rows past the last pixel / frame are dead
+  auto row_px = [&](int row) { return (long)(P > 1 ? row >> logf : 0); };
+  auto row_fr = [&](int row) { return P > 1 ? row & (F - 1) : row; };
+  auto row_ok = [&](int row) { return (P > 1 || row < F) && px0 + row_px(row) < p.hw; };
 
-  const half_t* qb = p.q + smp * p.q_bs + px * p.q_ps + head * 64;
-  const half_t* kb = p.k + smp * p.k_bs + px * p.k_ps + head * 64;
-  const half_t* vb = p.v + smp * p.v_bs + px * p.v_ps + head * 64;
+  const half_t* qb = p.q + smp * p.q_bs + px0 * p.q_ps + head * 64;
+  const half_t* kb = p.k + smp * p.k_bs + px0 * p.k_ps + head * 64;
+  const half_t* vb = p.v + smp * p.v_bs + px0 * p.v_ps + head * 64;
 
-  // V: 32 frames x 8 chunks = 256 chunks, 4 per lane, transposed into the wave-private LDS image
+  // V: 32 rows x 8 chunks = 256 chunks, 4 per lane, transposed into the wave-private LDS image
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = lane + 64 * i;
     const int key = c >> 3, dc = c & 7;
     half8_t vr = zero8;
-    if (key < F) vr = *reinterpret_cast<const half8_t*>(vb + (long)key * p.v_ts + dc * 8);
+    if (row_ok(key)) vr = *reinterpret_cast<const half8_t*>(vb + row_px(key) * p.v_ps + (long)row_fr(key) * p.v_ts + dc * 8);
     const int g = (((key >> 4) & 1) * 2) + ((key >> 2) & 1), j = vt_slot_elem(key);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -261,16 +270,18 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
       *reinterpret_cast<half_t*>(Vs + d * TVPITCH + ((g ^ ((d >> 3) & 3)) * 16) + j * 2) = vr[e];
     }
   }
-  // S^T = K Q^T straight from global (frame r, 16-byte pieces); rows >= F are zero
+  // S^T = K Q^T straight from global (row r, 16-byte pieces); dead rows are zero
   f32x16 st;
 #pragma unroll
   for (int e = 0; e < 16; ++e) st[e] = 0.f;
+  const bool rok = row_ok(r);
+  const long koff = row_px(r) * p.k_ps + (long)row_fr(r) * p.k_ts, qoff = row_px(r) * p.q_ps + (long)row_fr(r) * p.q_ts;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     half8_t kf = zero8, qf = zero8;
-    if (r < F) {
-      kf = *reinterpret_cast<const half8_t*>(kb + (long)r * p.k_ts + 16 * s + 8 * h);
-      qf = *reinterpret_cast<const half8_t*>(qb + (long)r * p.q_ts + 16 * s + 8 * h);
+    if (rok) {
+      kf = *reinterpret_cast<const half8_t*>(kb + koff + 16 * s + 8 * h);
+      qf = *reinterpret_cast<const half8_t*>(qb + qoff + 16 * s + 8 * h);
     }
     st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, st, 0, 0, 0);
   }
@@ -278,7 +289,9 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int key = 8 * (e >> 2) + 4 * h + (e & 3);
-    const float sv = key < F ? st[e] * p.scale_log2 : -INFINITY;  // F <= 32 keys: one tile, no running state
+    // one tile, no running state: a key counts for this lane's query iff it is a live row of the same pixel
+    const bool ok = P > 1 ? (key >> logf) == (r >> logf) : key < F;
+    const float sv = ok ? st[e] * p.scale_log2 : -INFINITY;
     st[e] = sv;
     mx = fmaxf(mx, sv);
   }
@@ -312,8 +325,8 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
       ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, ot[dt], 0, 0, 0);
     }
   }
-  if (active && r < F) {
-    half_t* op = p.out + smp * p.o_bs + px * p.o_ps + (long)r * p.o_ts + head * 64;
+  if (active && rok) {
+    half_t* op = p.out + smp * p.o_bs + (px0 + row_px(r)) * p.o_ps + (long)row_fr(r) * p.o_ts + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -375,13 +388,16 @@ extern "C" int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream) {
   a.q_bs = d->q_bs; a.q_ps = d->q_ps; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_ps = d->k_ps; a.k_ts = d->k_ts;
   a.v_bs = d->v_bs; a.v_ps = d->v_ps; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_ps = d->o_ps; a.o_ts = d->o_ts;
   a.nsample = d->nsample; a.hw = d->hw; a.heads = d->heads; a.frames = d->frames;
-  a.ntask = (long)d->nsample * d->hw * d->heads;
+  a.logf = d->frames == 8 ? 3 : d->frames == 16 ? 4 : 5;
+  a.logp = d->frames == 8 ? 2 : d->frames == 16 ? 1 : 0;
+  a.pgroups = (d->hw + (1 << a.logp) - 1) >> a.logp;
+  a.ntask = (long)d->nsample * a.pgroups * d->heads;
   a.scale_log2 = 0.125f * 1.4426950408889634f;
   const long nblk = (a.ntask + 3) / 4;
   MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "temporal_attn: grid too large");
   hipStream_t s = (hipStream_t)stream;
   // algorithmic bytes: q, k, v read + out written once
-  MvocProfScope prof(MVOC_FAM_TATTN, s, 4.0 * a.ntask * d->frames * 64 * 2);
+  MvocProfScope prof(MVOC_FAM_TATTN, s, 4.0 * (double)d->nsample * d->hw * d->heads * d->frames * 64 * 2);
   hipLaunchKernelGGL(tattn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, a);
   return mvoc_check_launch("tattn_kernel");
 }

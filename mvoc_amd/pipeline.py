@@ -143,6 +143,8 @@ class I2VGenXLPipeline:
         self._guidance_scale = 1.0
         self._graphs = {}
         self.max_cached_graphs = 4
+        self._concurrent_states = {}  # invert_concurrent: one captured iteration per concurrent clip
+        self._streams = []
         self.latent_cache = LatentCache(unet.device)
 
     # ---- reference plumbing ------------------------------------------------------------------------
@@ -228,6 +230,7 @@ class I2VGenXLPipeline:
         self.unet.set_frame_shard(shard)
         self.use_graphs = False
         self._graphs = {}
+        self._concurrent_states = {}
         self.latent_cache.write_files = shard.rank == 0
         return self
 
@@ -354,6 +357,61 @@ class I2VGenXLPipeline:
         self._run_stock_loop(lat, cond, num_inference_steps, guidance_scale, on_step=on_step)
         self.latent_cache.flush()
         return [torch.stack(list(reversed(s_)), 1) for s_ in seqs]
+
+    @torch.no_grad()
+    def invert_concurrent(self, prompts, images, latents, output_dirs, height=704, width=1280, target_fps=16, num_frames=16,
+                          num_inference_steps=50, guidance_scale=1.0, negative_prompt=None):
+        """DDIM-invert several source clips AT THE SAME TIME, each in its own batch-1 loop on its own HIP stream.  The
+        per-object inversions of a composition job are independent (``inverse.py:136-190`` runs them one after another; on a
+        node they shard one per GPU): on one GPU their kernels interleave, and wherever a batch-1 launch cannot fill the chip --
+        the 16x16 / 8x8 levels run 80-240 workgroups on 256 CUs, the small norm / statistics kernels are latency-bound -- another
+        clip's kernels take the idle CUs.  Every clip still runs exactly the launches of ``invert`` (one captured iteration per
+        clip), so its latents and files are BIT-IDENTICAL to a sequential run; only the schedule differs (measured: 32.5 -> 26.6 ms
+        per clip-step at three clips, profiles/r4).  Same return value per clip as ``invert``."""
+        n = len(prompts)
+        if not (len(images) == len(latents) == len(output_dirs) == n and n > 0):
+            raise ValueError("invert_concurrent: prompts, images, latents and output_dirs must have the same length")
+        if self.unet.shard is not None:
+            raise NotImplementedError("invert_concurrent: frame-sharded clips run one at a time")
+        self._guidance_scale = guidance_scale
+        sched = self.scheduler
+        sched.set_timesteps(num_inference_steps, device=self.device)
+        table, index = sched.coef_table(self.device, guidance_scale)
+        if any(self.unet.injection_flags()):
+            raise RuntimeError("stock loop with PnP hooks armed: call register_time_all(pipe, None, None) first")
+        states, seqs = [], [[] for _ in range(n)]
+        for j in range(n):
+            cond = self._stock_conditioning(prompts[j], negative_prompt, images[j], num_frames, height, width, target_fps, None, None,
+                                            None, None)
+            lat = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, None, latents[j])
+            key = ("stock-concurrent", j, tuple(lat.shape), guidance_scale > 1, bool(self.use_graphs),
+                   tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
+            st = self._concurrent_states.get(key)
+            if st is None:
+                st = self._concurrent_states[key] = self._make_stock_step(key, lat, cond, guidance_scale)
+            else:
+                st["load_cond"](cond)
+            st["latents"].copy_(lat)
+            states.append(st)
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream()
+        for s_ in self._streams[:n]:
+            s_.wait_stream(cur)
+        for t in sched.timesteps:
+            row = table[index[int(t)]]
+            for j, (st, s_) in enumerate(zip(states, self._streams)):
+                with torch.cuda.stream(s_):  # everything of clip j -- the two small fills, the replay, the snapshot -- on stream j
+                    st["t"].fill_(float(t))
+                    st["coef"].copy_(row)
+                    st["run"]()
+                    snap = st["latents"].clone()
+                    seqs[j].append(snap)
+                    self.latent_cache.put(output_dirs[j], int(t), snap)
+        for s_ in self._streams[:n]:
+            cur.wait_stream(s_)
+        self.latent_cache.flush()
+        return [torch.stack(list(reversed(q)), 1) for q in seqs]
 
     @torch.no_grad()
     def __call__(self, prompt=None, image=None, height=704, width=1280, target_fps=16, num_frames=16,

@@ -164,7 +164,7 @@ def _from_rows(r, n, h, w):
     return r.reshape(n, h, w, -1).permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 81, 82])
 @pytest.mark.parametrize("cin,cout,h,w,stride", [(64, 64, 8, 8, 1), (32, 96, 7, 9, 1), (64, 128, 9, 6, 2), (8, 64, 8, 8, 1)])
 def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     if tile and cin % 64:
@@ -182,7 +182,7 @@ def test_conv3x3(ops, cin, cout, h, w, stride, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 81, 82])
 def test_conv3x3_concat_glds(ops, tile):
     """two-source gather (decoder skip concat) with both channel counts multiples of 64"""
     from mvoc_amd.unet import pack_conv3x3
@@ -230,7 +230,7 @@ def test_conv3x3_upsample(ops, size, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
-@pytest.mark.parametrize("tile", [0, 11, 13, 61, 63, 81, 82])
+@pytest.mark.parametrize("tile", [0, 11, 13, 61, 81, 82])
 @pytest.mark.parametrize("frames", [1, 3, 16])
 def test_tconv3(ops, frames, tile):
     from mvoc_amd.unet import pack_tconv

@@ -367,6 +367,19 @@ def test_invert_many_matches_separate_inversions(tmp_path):
             assert (a.float() - torch.load(tmp_path / f"s{j}" / f"ddim_latents_{t}.pt").float()).abs().max() < 3e-2
     with pytest.raises(NotImplementedError):
         pipe.invert_many(prompts, images, x0, ["a", "b", "c"], **dict(kw, guidance_scale=7.5))
+    # the three clips as three concurrent batch-1 loops on three HIP streams: each clip replays exactly the launches of invert()
+    # -> return values and files BIT-IDENTICAL to the one-by-one pass (twice: the second call reuses the captured iterations)
+    for rep in range(2):
+        conc = pipe.invert_concurrent(prompts, images, x0, [str(tmp_path / f"c{rep}{j}") for j in range(3)], **kw)
+        for j in range(3):
+            assert torch.equal(conc[j], single[j]), (rep, j)
+            for t in (1, 201, 401, 601, 801):
+                assert torch.equal(torch.load(tmp_path / f"c{rep}{j}" / f"ddim_latents_{t}.pt"), torch.load(tmp_path / f"s{j}" / f"ddim_latents_{t}.pt"))
+    # ... with classifier-free guidance too (the stock iteration duplicates the sample), and a single clip
+    g75 = dict(kw, guidance_scale=7.5)
+    s75 = pipe.invert(prompt=prompts[0], image=images[0], latents=x0[0], return_dict=False, output_dir=None, **g75)
+    c75 = pipe.invert_concurrent(prompts[:1], images[:1], x0[:1], [None], **g75)
+    assert torch.equal(c75[0], s75)
 
 
 # ---- G8: the HIP pipeline's loops against the REFERENCE's own loops (tests/golden/g8_loops.npz) -----------------------
