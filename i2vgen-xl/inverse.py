@@ -71,8 +71,8 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
     (``I2VGenXLPipeline.invert_many``) before the per-entry pass below, which then finds their latents on disk.
     --concurrent_entries N (``concurrent``): the same grouping, but every clip keeps its own batch-1 loop and the N loops run at
     the same time on N HIP streams (``I2VGenXLPipeline.invert_concurrent``): files bit-identical to the one-by-one pass."""
-    pending = []
-    for entry in configs_list:
+    pending, done = [], set()  # done: output directories this pass produces (the per-entry pass must not invert them again,
+    for entry in configs_list:  #       also not under force_recompute_latents)
         if not entry["active"]:
             continue
         config = OmegaConf.merge(template_config, OmegaConf.create(entry))
@@ -88,6 +88,7 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
             first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
         key = (tuple(inv.image_size), inv.n_frames, inv.n_steps, inv.target_fps, str(inv.negative_prompt))
         pending.append((key, inv, first_frame, frame_list))
+        done.add(os.path.abspath(config.output_dir))
     pipe.scheduler = inverse_scheduler
     while pending:
         key = pending[0][0]
@@ -101,19 +102,21 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
         run([g_[1].prompt for g_ in group], [g_[2] for g_ in group], lat, [g_[1].output_dir for g_ in group],
             height=inv0.image_size[1], width=inv0.image_size[0], target_fps=inv0.target_fps, num_frames=inv0.n_frames,
             num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt)
+    return done
 
 
-def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1, concurrent_entries=1):
+def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1, concurrent_entries=3):
     pipe = build_pipeline(device, synthetic)
     if frame_shard is not None:
         pipe.enable_frame_shard(frame_shard)
     g = torch.Generator().manual_seed(template_config.seed)
     inverse_scheduler = DDIMInverseScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
     ddim_scheduler = DDIMScheduler.from_pretrained(PRETRAINED_MODEL_PATH, subfolder="scheduler")
+    inverted = set()
     if batch_entries > 1:
-        batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch_entries)
+        inverted = batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch_entries)
     elif concurrent_entries > 1 and frame_shard is None:
-        batched_inversions(pipe, inverse_scheduler, template_config, configs_list, concurrent_entries, concurrent=True)
+        inverted = batched_inversions(pipe, inverse_scheduler, template_config, configs_list, concurrent_entries, concurrent=True)
     for entry in configs_list:
         if not entry["active"]:
             logger.info(f"Skipping config_entry: {entry}")
@@ -128,7 +131,9 @@ def main(template_config, configs_list, device, synthetic=False, frame_shard=Non
             frame_list = [frame_list[0]] * config.n_frames
         if config.inverse_config.null_image_inversion:
             first_frame = Image.new("RGB", (config.image_size[0], config.image_size[1]), (0, 0, 0))
-        if os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False):
+        if os.path.abspath(config.output_dir) in inverted:
+            logger.info(f"### {config.output_dir}: inverted by the grouped pass above")
+        elif os.path.exists(config.output_dir) and not config.get("force_recompute_latents", False):
             logger.info(f"### Skipping !!! {config.output_dir} already exists. ")
         else:
             ddim_inversion(config.inverse_config, first_frame, frame_list, pipe, inverse_scheduler, g)
