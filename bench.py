@@ -165,10 +165,13 @@ class Job:
         pipe = self.pipe
         saved, pipe._guidance_scale = pipe._guidance_scale, 1.0
         saved_sched, pipe.scheduler = pipe.scheduler, self.inv_sched
-        self.inv_states = [self.inv_state]
-        for j in (1, 2):
-            cond = pipe._stock_conditioning("", "", f"source-{j}", self.F, self.h * 8, self.w * 8, 8, None, None, None, None)
-            self.inv_states.append(pipe._make_stock_step(f"bench-inv-{j}", self.inv_latents.flip(1 + j), cond, 1.0))
+        from mvoc_amd import ops
+        self.inv_states = []
+        with ops.gemm_concurrency(3):  # as invert_concurrent captures them: under-filled batch-1 GEMMs keep K in one piece
+            for j in (0, 1, 2):
+                cond = pipe._stock_conditioning("", "", f"source-{j}", self.F, self.h * 8, self.w * 8, 8, None, None, None, None)
+                lat = self.inv_latents.flip(1 + j) if j else self.inv_latents
+                self.inv_states.append(pipe._make_stock_step(f"bench-inv-{j}", lat, cond, 1.0))
         pipe._guidance_scale, pipe.scheduler = saved, saved_sched
         self.inv_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         self.concurrent = True

@@ -90,6 +90,11 @@ typedef struct mvoc_gemm_desc {
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
 /* 1 when this thread's most recent mvoc_gemm_f16 call wrote its descriptor's chan_sums */
 int mvoc_gemm_chan_sums_written(void);
+/* Scheduling hint for the tile / split-K choice of the calls that follow: the caller runs n independent launches of each shape at
+ * the same time on n streams (the job's per-object inversions, inverse.py:136-190 as concurrent loops), so an under-filled grid
+ * need not be split over K to fill the chip.  Process-wide, returns the previous value; 1 (the default) = alone.  Affects speed
+ * only: every choice computes the same function. */
+int mvoc_gemm_concurrency_hint(int n);
 /* scratch for the deterministic split-K form of a launch: the most the auto policy uses is 8 slices of m*n fp32
  * partials; 0 when the policy would never split this shape (m > 8192 or k < 2048).  Passing no workspace is always valid:
  * the launch then runs unsplit. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mvoc_gemm_f16": (i32, [C.POINTER(GemmDesc), vp]),
     "mvoc_gemm_workspace_bytes": (sz, [i64, i64, i64]),
     "mvoc_gemm_chan_sums_written": (i32, []),
+    "mvoc_gemm_concurrency_hint": (i32, [i32]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),

@@ -59,6 +59,21 @@ def _gemm(d: GemmDesc, dev=None, out=None, sums=False):
         out.chan_sums = cs  # rides on the tensor OBJECT: a view / slice / copy of it carries no statistics
 
 
+class gemm_concurrency:
+    """``with gemm_concurrency(n):`` -- the GEMM launches issued (or CAPTURED) inside run beside n - 1 independent launches of the
+    same shape on other streams (include/mvoc_hip.h: mvoc_gemm_concurrency_hint)"""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old = lib.mvoc_gemm_concurrency_hint(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        lib.mvoc_gemm_concurrency_hint(self.old)
+
+
 def chan_sums_of(x, rows_per_sample):
     """the producer's per-slab channel sums of the rows in ``x`` if the GEMM that wrote it emitted them and they fit the norm"""
     cs = getattr(x, "chan_sums", None)

@@ -360,14 +360,18 @@ class I2VGenXLPipeline:
 
     @torch.no_grad()
     def invert_concurrent(self, prompts, images, latents, output_dirs, height=704, width=1280, target_fps=16, num_frames=16,
-                          num_inference_steps=50, guidance_scale=1.0, negative_prompt=None):
+                          num_inference_steps=50, guidance_scale=1.0, negative_prompt=None, concurrency_hint=True):
         """DDIM-invert several source clips AT THE SAME TIME, each in its own batch-1 loop on its own HIP stream.  The
         per-object inversions of a composition job are independent (``inverse.py:136-190`` runs them one after another; on a
         node they shard one per GPU): on one GPU their kernels interleave, and wherever a batch-1 launch cannot fill the chip --
         the 16x16 / 8x8 levels run 80-240 workgroups on 256 CUs, the small norm / statistics kernels are latency-bound -- another
         clip's kernels take the idle CUs.  Every clip still runs exactly the launches of ``invert`` (one captured iteration per
-        clip), so its latents and files are BIT-IDENTICAL to a sequential run; only the schedule differs (measured: 32.5 -> 26.6 ms
-        per clip-step at three clips, profiles/r4).  Same return value per clip as ``invert``."""
+        clip); replaying the n iterations concurrently or one after the other gives bit-identical latents and files (measured:
+        32.5 -> 26.7 ms per clip-step at three clips, profiles/r4).  ``concurrency_hint`` (default): the iterations are captured
+        with ``mvoc_gemm_concurrency_hint(n)``, so GEMMs whose batch-1 grid cannot fill the chip keep their K in one piece (no
+        split-K slabs / reduce pass: the other clips fill the idle CUs) -- 25.5 ms per clip-step; against ``invert`` those GEMMs
+        then sum in another order (rel-L2 5e-5 after a step on the 1.42 B network); ``False`` keeps ``invert``'s launches exactly
+        (bit-identical to it).  Same return value per clip as ``invert``."""
         n = len(prompts)
         if not (len(images) == len(latents) == len(output_dirs) == n and n > 0):
             raise ValueError("invert_concurrent: prompts, images, latents and output_dirs must have the same length")
@@ -384,11 +388,13 @@ class I2VGenXLPipeline:
             cond = self._stock_conditioning(prompts[j], negative_prompt, images[j], num_frames, height, width, target_fps, None, None,
                                             None, None)
             lat = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, None, latents[j])
-            key = ("stock-concurrent", j, tuple(lat.shape), guidance_scale > 1, bool(self.use_graphs),
+            hint = n if concurrency_hint else 1
+            key = ("stock-concurrent", j, hint, tuple(lat.shape), guidance_scale > 1, bool(self.use_graphs),
                    tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
             st = self._concurrent_states.get(key)
             if st is None:
-                st = self._concurrent_states[key] = self._make_stock_step(key, lat, cond, guidance_scale)
+                with ops.gemm_concurrency(hint):  # (baked into the captured iteration: tile / split-K choices)
+                    st = self._concurrent_states[key] = self._make_stock_step(key, lat, cond, guidance_scale)
             else:
                 st["load_cond"](cond)
             st["latents"].copy_(lat)

@@ -10,10 +10,14 @@ job = bench.Job("cuda:0", 16, 64, True)
 pipe = job.pipe
 pipe._guidance_scale = 1.0
 pipe.scheduler = job.inv_sched
-states = [job.inv_state]
-for j in (1, 2):
-    cond = pipe._stock_conditioning("", "", f"source-{j}", 16, 512, 512, 8, None, None, None, None)
-    states.append(pipe._make_stock_step(f"bench-inv-{j}", job.inv_latents.flip(2 + j - 1), cond, 1.0))
+from mvoc_amd import ops
+HINT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # capture the three iterations under mvoc_gemm_concurrency_hint(HINT)
+states = []
+with ops.gemm_concurrency(HINT):
+    for j in (0, 1, 2):
+        cond = pipe._stock_conditioning("", "", f"source-{j}", 16, 512, 512, 8, None, None, None, None)
+        states.append(pipe._make_stock_step(f"bench-inv-{j}", job.inv_latents.flip(2 + j - 1) if j else job.inv_latents, cond, 1.0))
+print("captured under concurrency hint", HINT)
 t = int(job.inv_sched.timesteps[0])
 for st in states:
     st["t"].fill_(float(t)); st["coef"].copy_(job.inv_table[job.inv_index[t]])
@@ -55,3 +59,16 @@ print("bit-identical:", [bool(torch.equal(x, y)) for x, y in zip(a, b)])
 for st, l in zip(states, lat0): st["latents"].copy_(l)
 seq(1); torch.cuda.synchronize(); c = [st["latents"].clone() for st in states]
 print("sequential twice bit-identical:", [bool(torch.equal(x, y)) for x, y in zip(a, c)])
+
+if HINT > 1:  # the same three clips captured WITHOUT the hint: how far apart are the two sets after one step?
+    plain = []
+    for j in (0, 1, 2):
+        cond = pipe._stock_conditioning("", "", f"source-{j}", 16, 512, 512, 8, None, None, None, None)
+        plain.append(pipe._make_stock_step(f"bench-inv-plain-{j}", job.inv_latents.flip(2 + j - 1) if j else job.inv_latents, cond, 1.0))
+    for st, l in zip(plain, lat0):
+        st["latents"].copy_(l); st["t"].fill_(float(t)); st["coef"].copy_(job.inv_table[job.inv_index[t]])
+        st["run"]()
+    torch.cuda.synchronize()
+    for j, (st, x) in enumerate(zip(plain, a)):
+        d = (st["latents"].float() - x.float())
+        print(f"clip {j}: hinted vs plain capture after one step: max abs {float(d.abs().max()):.3e}, rel-L2 {float(d.norm() / x.float().norm()):.3e}")
