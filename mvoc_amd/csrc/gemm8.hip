@@ -470,8 +470,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   //   tile's <= RA_ROWS samples) are fetched ONCE per block into an LDS table (request_table above) and read from LDS where they
   //   are used (round 3 fetched them per pass into 40-50 registers: two more L2 round trips per block, and no room to issue
   //   anything else early);
-  // * the residual chunks of BOTH passes are requested before pass 0's arithmetic where the registers allow (256-wide), pass 1's
-  //   at the latest before pass 0's stores: vmcnt retires in issue order, a load issued behind the 8 / 10 stores of pass 0
+  // * the residual chunks of pass 0 are requested before pass 0's arithmetic, those of pass 1 too where the registers allow
+  //   (256-wide), at the latest before pass 0's stores: vmcnt retires in issue order, a load issued behind the 8 / 10 stores of pass 0
   //   waits for their acknowledgement under the chip-wide store burst (phase stamps, 320-wide: pass 1 20 k ticks against 12 k).
   const bool geglu = EPI == 0 ? p.act == MVOC_ACT_GEGLU : EPI == 3;
   const bool use_ln = EPI == 0 ? p.ln_s != nullptr : EPI >= 2;
@@ -600,7 +600,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)r8[e]);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(a, lane2, it, p.ldo), 0, G8_NT_STORE ? 2 : 0);
+      // non-temporal only where a store instruction writes whole 128-byte lines (256-wide: 64 channels per pass).  The 320-wide
+      // tile's passes are 160 bytes per pixel row: every line but the first and last of a row is written in two pieces by two
+      // passes / waves, and as streaming stores those pieces do not merge in L2 -- phase stamps: readback + stores 20-30 k ticks
+      // per pass against 4-5 k with plain stores (launch 230 -> 218 us at K = 960, 288 -> 262 with a residual); the 256-wide
+      // tile with plain stores loses 15 % instead (its stores then evict operand lines: 2 734 -> 3 242 ticks per K tile)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(a, lane2, it, p.ldo), 0, (G8_NT_STORE && XT == 4) ? 2 : 0);
       if (p.stats && it < nchunk) *reinterpret_cast<half8_t*>(epi + px * PITCH + c * 16) = v;  // the STORED values, for stats_pass
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
@@ -642,12 +647,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     u32x4 r0[XT * 2], r1[XT * 2];
     g8_wait_vm<0>();  // the table has landed (256-wide: long ago; this wave's piece -- the barrier makes it every wave's)
     G8_BAR();
-    if constexpr (XT == 4) { load_resid(0, r0, 0, XT * 2); load_resid(1, r1, 0, XT * 2); }
+    load_resid(0, r0, 0, XT * 2);  // pass 0's residual chunks fly under pass 0's arithmetic in both forms
+    if constexpr (XT == 4) load_resid(1, r1, 0, XT * 2);
     __builtin_amdgcn_sched_barrier(0);
     arith(I0{});
     G8_STAMP(6);
     __builtin_amdgcn_sched_barrier(0);  // (320-wide: 160 live accumulators until here)
-    if constexpr (XT != 4) { load_resid(0, r0, 0, XT * 2); load_resid(1, r1, 0, R1_EARLY); }
+    if constexpr (XT != 4) load_resid(1, r1, 0, R1_EARLY);
     __builtin_amdgcn_sched_barrier(0);
     readback_store(0, r0);
     G8_STAMP(3);

@@ -11,13 +11,14 @@ pipe = job.pipe
 pipe._guidance_scale = 1.0
 pipe.scheduler = job.inv_sched
 from mvoc_amd import ops
-HINT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # capture the three iterations under mvoc_gemm_concurrency_hint(HINT)
+HINT = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # capture the iterations under mvoc_gemm_concurrency_hint(HINT)
+NCLIP = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 states = []
 with ops.gemm_concurrency(HINT):
-    for j in (0, 1, 2):
+    for j in range(NCLIP):
         cond = pipe._stock_conditioning("", "", f"source-{j}", 16, 512, 512, 8, None, None, None, None)
-        states.append(pipe._make_stock_step(f"bench-inv-{j}", job.inv_latents.flip(2 + j - 1) if j else job.inv_latents, cond, 1.0))
-print("captured under concurrency hint", HINT)
+        states.append(pipe._make_stock_step(f"bench-inv-{j}", job.inv_latents.flip(2 + j % 3) if j else job.inv_latents, cond, 1.0))
+print("captured under concurrency hint", HINT, "clips", NCLIP)
 t = int(job.inv_sched.timesteps[0])
 for st in states:
     st["t"].fill_(float(t)); st["coef"].copy_(job.inv_table[job.inv_index[t]])
@@ -42,11 +43,11 @@ def conc(n):
 def timeit(fn, n):
     fn(2); torch.cuda.synchronize()
     t0 = time.perf_counter(); fn(n); torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / (3 * n) * 1e3
+    return (time.perf_counter() - t0) / (len(states) * n) * 1e3
 
 fresh = [st["latents"].clone() for st in states]
 for rnd in range(3):
-    print(f"round {rnd}: sequential {timeit(seq, 10):.2f} ms per inversion step | three streams {timeit(conc, 10):.2f} ms per inversion step", flush=True)
+    print(f"round {rnd}: sequential {timeit(seq, 10):.2f} ms per inversion step | concurrent streams {timeit(conc, 10):.2f} ms per inversion step", flush=True)
 # same results?
 lat0 = fresh
 print("finite start:", all(bool(torch.isfinite(l).all()) for l in lat0))
@@ -60,7 +61,7 @@ for st, l in zip(states, lat0): st["latents"].copy_(l)
 seq(1); torch.cuda.synchronize(); c = [st["latents"].clone() for st in states]
 print("sequential twice bit-identical:", [bool(torch.equal(x, y)) for x, y in zip(a, c)])
 
-if HINT > 1:  # the same three clips captured WITHOUT the hint: how far apart are the two sets after one step?
+if HINT > 1 and NCLIP == 3:  # the same three clips captured WITHOUT the hint: how far apart are the two sets after one step?
     plain = []
     for j in (0, 1, 2):
         cond = pipe._stock_conditioning("", "", f"source-{j}", 16, 512, 512, 8, None, None, None, None)
