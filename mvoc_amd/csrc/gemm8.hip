@@ -25,6 +25,8 @@
 //   carry an offset beyond the resource's range -- the hardware range check returns zeros.  No per-issue vector ALU work.
 // * Epilogue: arithmetic in the accumulator layout, fp16 result parked in a wave-private LDS tile, read back as 16-byte row
 //   chunks, residual added, stored (same rounding points as gemm_epilogue_lds).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "gemm_args.h"
@@ -120,8 +122,24 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned logical = g8_udiv(logical0, p.mg_sk, p.sh_sk);
   const int slice = (int)(logical0 - logical * (unsigned)p.split_k);
-  const unsigned mtile = g8_udiv(logical, p.mg_nt, p.sh_nt);
-  const int n0 = (int)(logical - mtile * (unsigned)p.n_tiles) * BX;
+  // Tile order inside an XCD's contiguous range of logical ids (xcd_remap): bands of `band` m-tiles, inside a band m fastest.
+  // The 32 blocks an XCD runs at a time then form a band x (32 / band) patch of the tile grid and share band activation panels
+  // and 32 / band weight panels through the XCD's L2, instead of 32 / n_tiles m-tiles x ALL n-tiles (n fastest: every m-tile of
+  // a 20-n-tile GEGLU launch re-streamed all 6.5 MB of weights past the 4 MB L2 -- 715 MB fetched for 105 + 6.5 MB of operands,
+  // profiles/r4/pmc_gemm_traffic.json).  band = 1 is the old order.
+  unsigned mtile, ntile;
+  if (p.band > 1) {
+    const unsigned per = (unsigned)p.band * (unsigned)p.n_tiles;
+    const unsigned b_ = g8_udiv(logical, p.mg_band, p.sh_band);
+    const unsigned idx = logical - b_ * per;
+    const unsigned rows = min((unsigned)p.band, (unsigned)p.m_tiles - b_ * (unsigned)p.band);
+    ntile = idx / rows;  // (scalar; rows <= band)
+    mtile = b_ * (unsigned)p.band + (idx - ntile * rows);
+  } else {
+    mtile = g8_udiv(logical, p.mg_nt, p.sh_nt);
+    ntile = logical - mtile * (unsigned)p.n_tiles;
+  }
+  const int n0 = (int)ntile * BX;
   const int m0 = (int)mtile * 256;
   const int kbeg = slice * p.k_per_split;
   const int nk = p.k_per_split / 64;
@@ -705,6 +723,12 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
   a.n_tiles = (a.N + BX - 1) / BX;
   a.m_tiles = (a.M + 255) / 256;
   g8_magic((unsigned)a.n_tiles, a.mg_nt, a.sh_nt);
+  {
+    static const int force = getenv("MVOC_G8_BAND") ? atoi(getenv("MVOC_G8_BAND")) : 0;  // diagnostics: 1 = the n-fastest order
+    a.band = force ? force : (a.n_tiles >= 8 ? 4 : a.n_tiles >= 4 ? 2 : 1);
+    if (a.band > a.m_tiles) a.band = 1;
+    g8_magic((unsigned)(a.band * a.n_tiles), a.mg_band, a.sh_band);
+  }
   g8_magic((unsigned)a.split_k, a.mg_sk, a.sh_sk);
   g8_magic((unsigned)(a.hout * a.wout), a.mg_hwout, a.sh_hwout);
   g8_magic((unsigned)a.wout, a.mg_wout, a.sh_wout);

@@ -28,8 +28,9 @@ struct GemmArgs {
   float* ws;                 // fp32 partial slabs [split_k][M][N] (deterministic: summed in slice order by splitk_reduce)
   // gemm8: divisions by launch constants as multiply-high + shift (g8_magic; sh < 0: divisor 1) -- the block's tile
   // coordinates and the (image, y, x) / frame of every staged row took ~20 integer divisions (~40 instructions each) in the prologue
-  unsigned mg_nt, mg_sk, mg_hwout, mg_wout, mg_hw, mg_fr, mg_ra;
-  int sh_nt, sh_sk, sh_hwout, sh_wout, sh_hw, sh_fr, sh_ra;
+  unsigned mg_nt, mg_sk, mg_hwout, mg_wout, mg_hw, mg_fr, mg_ra, mg_band;
+  int sh_nt, sh_sk, sh_hwout, sh_wout, sh_hw, sh_fr, sh_ra, sh_band;
+  int band;  // gemm8 tile order: m-tiles per band (gemm8.hip)
   float* stats;  // gemm8, optional: per 256-row tile and output channel {sum, sum of squares} of the stored values, fp32 [m_tiles][n_store][2]
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
