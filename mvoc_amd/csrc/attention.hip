@@ -34,6 +34,7 @@ struct AttnArgs {
   int nbatch, heads, tq, tk, kv_bdiv, causal;
   float scale_log2;
   long v2_off, o2_off;  // NV == 2: element offsets of the pair's second V / output (same Q and K)
+  int qblocks;          // 128-query blocks per (batch entry, head)
 };
 
 __device__ __forceinline__ int vt_slot_group(int key) {  // 16-byte group (8 slots) of a key inside its 32-key tile
@@ -59,8 +60,13 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
   char* Vs = smem + 64 * KPITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // 1-D grid, XCD-aware: the query blocks of one (batch entry, head) share its K / V (1 MB at 4 096 keys) and get consecutive
+  // logical ids, i.e. one XCD's L2 (round-robin dispatch: a 3-D grid spread them over all eight and every XCD fetched the K / V
+  // of every (entry, head) for itself)
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned qb_ = logical % (unsigned)p.qblocks, hb_ = logical / (unsigned)p.qblocks;
+  const int head = (int)(hb_ % (unsigned)p.heads), b = (int)(hb_ / (unsigned)p.heads);
+  const int q0 = (int)qb_ * 128 + wave * 32;
 
   const half_t* qp = p.q + (long)b * p.q_bs + head * D;
   const int qrow = min(q0 + r, p.tq - 1);
@@ -360,7 +366,10 @@ extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // (work = what the reference computes: the paired form stands for two attentions)
   MvocProfScope prof(MVOC_FAM_FLASH, s, (d->v2 ? 2.0 : 1.0) * 4.0 * d->nbatch * d->heads * (double)d->tq * d->tk * hd);
-  dim3 grid((d->tq + 127) / 128, d->heads, d->nbatch);
+  a.qblocks = (d->tq + 127) / 128;
+  const long nblk = (long)a.qblocks * d->heads * d->nbatch;
+  MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "flash_attn: grid too large");
+  dim3 grid((unsigned)nblk);
   a.v2_off = a.o2_off = 0;
   if (d->v2) {
     MVOC_REQUIRE(d->out2 && hd == 64, -2, "flash_attn: the paired form needs out2 and head_dim 64");
