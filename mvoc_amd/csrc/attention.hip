@@ -48,11 +48,24 @@ __device__ __forceinline__ int vt_slot_elem(int key) { return ((key >> 3) & 1) *
 // of a 4096-key row (32 multiplies + an exponential per lane each time); with the threshold on the first tile or two only.
 constexpr float FLASH_THR = 8.0f;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max of a value with the other half-wave's (lane ^ 32): v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another in the vector pipe (the ds_bpermute form of __shfl_xor is an LDS round trip on the per-tile critical path)
+__device__ __forceinline__ float flash_xhalf_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
+
 // NV = 2: TWO value tensors attend with the same Q and K (the PnP destination pair: pnp_utils.py:664-668 writes one blended
 // q / k into both the unconditional and the conditional chunk, so softmax(q k^T) is computed once and multiplied into both V's;
 // per tile 16 more MFMAs instead of a second S^T + softmax + PV pass).  Outputs are bit-identical to two NV = 1 launches.
 template <int D, int NV>  // head dim: 64 (the UNet), 96 (CLIP ViT-H's 80, zero-padded by the projection weights)
-__global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
+// head dim 64, one V: 128 registers = four waves per SIMD (130 without the bound; +2 % at T = 4 096, +4-6 % at 1 024 / 256, same box)
+#ifndef FLASH_MINW
+#define FLASH_MINW 4
+#endif
+__global__ __launch_bounds__(256, (D == 64 && NV == 1) ? FLASH_MINW : 1) void flash_kernel(const AttnArgs p) {
   constexpr int KPITCH = FlashPitch<D>::K, VPITCH = FlashPitch<D>::V;
   constexpr int ND = D / 16, NT = D / 32, CPK = D / 8, NCH = 64 * CPK / 256;  // k steps, output tiles, 16-byte chunks per key / thread
   __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + NV * 64 * VPITCH];
@@ -74,8 +87,19 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 #pragma unroll
   for (int s = 0; s < ND; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
 
-  const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * D;
-  const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * D;
+  // K / V rows of this (entry, head): a wave-uniform base (advanced per tile on the scalar unit) + a per-lane 32-bit byte offset
+  // computed once.  Rows past the last key (ragged last tile) are CLAMPED to the last row instead of zero-filled: their scores are
+  // masked to -inf below, so their probabilities are exactly 0 and 0 x (a finite V row) contributes exactly 0.
+  const char* kb = reinterpret_cast<const char*>(p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * D);
+  const char* vb = reinterpret_cast<const char*>(p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * D);
+  const unsigned k_rb = (unsigned)p.k_ts * 2u, v_rb = (unsigned)p.v_ts * 2u;  // row pitches in bytes
+  unsigned koff[NCH], voff[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * 256;
+    koff[i] = (unsigned)(c / CPK) * k_rb + (unsigned)(c % CPK) * 16u;
+    voff[i] = (unsigned)(c / CPK) * v_rb + (unsigned)(c % CPK) * 16u;
+  }
 
   f32x16 ot[NV][NT];
 #pragma unroll
@@ -88,20 +112,22 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 
   const int ntiles = (p.tk + 63) / 64;
   half8_t kreg[NCH], vreg[NV][NCH];
-  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int kt) {
+    const char* kt_ = kb + (size_t)kt * 64u * k_rb;
+    const char* vt_ = vb + (size_t)kt * 64u * v_rb;
+    const bool ragged = __builtin_amdgcn_readfirstlane(kt * 64 + 64 > p.tk);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * 256;
-      const int key = kt * 64 + c / CPK, dc = c % CPK;
-      kreg[i] = zero8;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) vreg[v][i] = zero8;
-      if (key < p.tk) {
-        kreg[i] = *reinterpret_cast<const half8_t*>(kb + (long)key * p.k_ts + dc * 8);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) vreg[v][i] = *reinterpret_cast<const half8_t*>(vb + v * p.v2_off + (long)key * p.v_ts + dc * 8);
+      unsigned ko = koff[i], vo = voff[i];
+      if (ragged) {
+        const int c = tid + i * 256;
+        const unsigned row = (unsigned)min(c / CPK, p.tk - 1 - kt * 64);
+        ko = row * k_rb + (unsigned)(c % CPK) * 16u;
+        vo = row * v_rb + (unsigned)(c % CPK) * 16u;
       }
+      kreg[i] = *reinterpret_cast<const half8_t*>(kt_ + ko);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) vreg[v][i] = *reinterpret_cast<const half8_t*>(vt_ + (size_t)v * (size_t)p.v2_off * 2u + vo);
     }
   };
   gload(0);
@@ -151,7 +177,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = flash_xhalf_max(mx);
     if (__any((mx - mrun) * p.scale_log2 > FLASH_THR)) {  // wave-uniform; always on the first tile (mrun = -inf)
       const float mnew = fmaxf(mrun, mx);
       const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2);
@@ -164,11 +190,16 @@ __global__ __launch_bounds__(256) void flash_kernel(const AttnArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) ot[v][dt][e] *= alpha;
     }
-    const float mc = mrun * p.scale_log2;
+    // exponent arguments two at a time (v_pk_fma_f32: the same fp32 fma per element, half the instructions)
+    const f32x2 sc2 = {p.scale_log2, p.scale_log2}, mc2 = {-mrun * p.scale_log2, -mrun * p.scale_log2};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[t][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][e], p.scale_log2, -mc));
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{st[t][e], st[t][e + 1]}, sc2, mc2);
+        st[t][e] = __builtin_amdgcn_exp2f(a[0]);
+        st[t][e + 1] = __builtin_amdgcn_exp2f(a[1]);
+      }
 
     // O^T += V^T P^T : accumulator registers 8s..8s+7 of tile t are the column operand of k-step (t, s)
 #pragma unroll
