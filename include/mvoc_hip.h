@@ -125,6 +125,10 @@ typedef struct mvoc_attn_desc {
 
 /* spatial self-attention and image/text cross-attention (flash-style, K/V tiles LDS-staged) */
 int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream);
+/* Kernel choice of the calls that follow (head_dim 64, no causal mask): -1 by key count (default: the software-pipelined kernel from
+ * 2 048 keys up), 0 never, 1 wherever it applies.  Process-wide; speed only -- both kernels return the same bits (the tests
+ * compare them).  Also settable at load time: MVOC_FLASH3=0|1. */
+void mvoc_flash_pipelined(int mode);
 /* temporal self-attention: one sequence per (sample, pixel), tq == tk == frames <= 32; "t" walks frames
  * (ts = H*W*C for the canonical layout), "b" walks sample*pixel via (b / hw)*bs + (b % hw)*ps */
 typedef struct mvoc_tattn_desc {

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mvoc_gemm_chan_sums_written": (i32, []),
     "mvoc_gemm_concurrency_hint": (i32, [i32]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
+    "mvoc_flash_pipelined": (None, [i32]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),
     "mvoc_xs_linear_f16": (i32, [C.POINTER(XsDesc), vp]),

@@ -18,6 +18,8 @@
 //   Same transposed-score scheme with a single 32x32 tile; V^T goes through a 4 KB wave-private LDS image.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256, (D == 64 && NV == 1) ? FLASH_MINW : 1) void fl
   __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + NV * 64 * VPITCH];
   char* Ks = smem;
   char* Vs = smem + 64 * KPITCH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: q0 below costs no vector register across the loop)
   const int r = lane & 31, h = lane >> 5;
   // 1-D grid, XCD-aware: the query blocks of one (batch entry, head) share its K / V (1 MB at 4 096 keys) and get consecutive
   // logical ids, i.e. one XCD's L2 (round-robin dispatch: a 3-D grid spread them over all eight and every XCD fetched the K / V
@@ -237,12 +240,357 @@ __global__ __launch_bounds__(256, (D == 64 && NV == 1) ? FLASH_MINW : 1) void fl
   }
   const float ltot = lrun + __shfl_xor(lrun, 32);
   const float inv = 1.0f / ltot;
+  // (the store addresses are formed from a lane index made opaque HERE: computed ahead of the loop, r and h cost registers across it
+  // -- the ones that did not fit four waves per SIMD)
+  int lane_e = tid;
+  asm volatile("" : "+v"(lane_e));
+  const int r_e = lane_e & 31, h_e = (lane_e >> 5) & 1;
+  if (q0 + r_e < p.tq) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      half_t* op = p.out + v * p.o2_off + (long)b * p.o_bs + (long)(q0 + r_e) * p.o_ts + head * D;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(ot[v][dt][q * 4 + e] * inv);
+          *reinterpret_cast<half4_t*>(op + 32 * dt + 8 * q + 4 * h_e) = o;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flash3_kernel -- the same attention (head dim 64, no causal mask) SOFTWARE-PIPELINED inside each wave, for long key rows.
+// tools/lab/overlap.hip: one wave that places ~7 vector instructions between consecutive MFMAs runs 16 MFMAs + 128 vector
+// instructions in the time of the 16 MFMAs alone + 25 %; flash_kernel's wave runs them in PHASES (S^T = 8 MFMAs behind their
+// fragment reads, then ~100 vector instructions of softmax with no MFMA in flight, then P V) and leaves the overlap to the other
+// waves of the SIMD: ~2 900 ticks per tile and wave for 512 matrix cycles.  Here:
+// * the tile loop is skewed by one tile: iteration t computes S^T of tile t + 1 (independent of everything else in the iteration)
+//   WHILE it takes the softmax of tile t, and O^T += V^T P^T of tile t as the probability fragments appear; two score accumulators
+//   (the loop is unrolled by two so they swap roles statically);
+// * the instruction order is dictated to hipcc's scheduler (sched_group_barrier pipelines): one MFMA, a handful of vector /
+//   transcendental instructions, the next MFMA ... -- its own order is all MFMAs first;
+// * K / V tiles arrive by LDS-DMA (buffer_load ... lds, 1 KB pieces = 8 keys x 128 B, two K + two V pieces per wave and tile)
+//   into a ring of NS stages, NS - 1 tiles ahead, behind a counted s_waitcnt vmcnt and ONE raw s_barrier per tile: no staging
+//   registers, no ds_write pass, no address arithmetic in the loop (per-lane offsets are loop constants, the tile advance is the
+//   instruction's scalar offset; rows past the last key are outside the buffer resource and read zeros).  Issued unconditionally,
+//   also past the last tile (out of range: zeros, no traffic), so the wait count is one constant.
+// * LDS images are unpadded (a DMA piece is contiguous): K rows 128 B with 16-byte chunk c of key r at c ^ ((r >> 1) & 7)
+//   (conflict-free b128 operand reads, as in the GEMM kernels); V rows 128 B with the two 64-byte halves of key r swapped when
+//   (r >> 1) & 1 -- the four keys of a transposing read then fall into four disjoint 64-byte bank windows.  Both swizzles are
+//   applied to the DMA's per-lane source offset and again on the read.
+// Same fragment maps, rounding points, summation order and deferred rescale as flash_kernel: outputs are bit-identical to it.
+#define F3_BAR()                         \
+  do {                                   \
+    __builtin_amdgcn_sched_barrier(0);   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define F3_FENCE() __builtin_amdgcn_sched_barrier(0)
+// scheduling groups (IGroupLP): one MFMA, then V plain vector and T transcendental instructions; R LDS reads
+#define F3_GRP(V, T)                                   \
+  do {                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, V, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x400, T, 0); \
+  } while (0)
+#define F3_RD(R) __builtin_amdgcn_sched_group_barrier(0x100, R, 0)
+#ifdef MVOC_F3_STAMPS  // diagnostic build (tools/dbg/f3_stamps.py): s_memtime accumulated per phase, block 0 wave 0
+__device__ unsigned long long f3_dbg[8];
+#define F3_STAMP(i)                                                                      \
+  do {                                                                                   \
+    unsigned long long t_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    if (blockIdx.x == 0 && tid == 0) { f3_acc[i] += t_ - f3_last; }                      \
+    f3_last = t_;                                                                        \
+  } while (0)
+#else
+#define F3_STAMP(i)
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KB at the wave-uniform LDS byte address `lds`), as an asm statement: hipcc makes every
+// transposing LDS read (ds_read_b64_tr_b16 has no memory operand it can disambiguate) wait vmcnt(0) for the LDS-DMA it knows to be
+// in flight -- the ring would drain on every tile (measured: 600 ns per tile).  Hidden here, the pieces are counted by the
+// kernel's own s_waitcnt vmcnt(N) only.  No VGPR destination: register-safe; M0 is saved, set and restored inside the statement.
+__device__ __forceinline__ void f3_dma(const u32x4 rsrc, unsigned voff, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds), "s"(rsrc) : "memory");
+}
+// buffer resource words for a raw buffer of `bytes` bytes at `base` (wave-uniform): range-checked, no swizzle
+__device__ __forceinline__ u32x4 f3_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void f3_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#ifndef F3_W1
+#define F3_W1 3
+#endif
+template <int NV>
+__global__ __launch_bounds__(256, NV == 1 ? F3_W1 : 2) void flash3_kernel(const AttnArgs p) {
+  constexpr int D = 64, NS = (NV == 1 && F3_W1 == 2) ? 4 : 3, TILE = 8192 * (1 + NV), PCS = 2 + 2 * NV;  // ring stages, bytes per stage, DMA pieces per wave and tile
+  __shared__ __attribute__((aligned(1024))) char smem[NS * TILE];
+#ifdef MVOC_F3_STAMPS
+  unsigned long long f3_acc[6] = {0, 0, 0, 0, 0, 0}, f3_last = 0, f3_t0, f3_r0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+#ifdef MVOC_F3_STAMPS
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(f3_t0), "=s"(f3_r0)::"memory");
+  f3_last = f3_t0;
+#endif
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned qb_ = logical % (unsigned)p.qblocks, hb_ = logical / (unsigned)p.qblocks;
+  const int head = (int)(hb_ % (unsigned)p.heads), b = (int)(hb_ / (unsigned)p.heads);
+  const int q0 = (int)qb_ * 128 + wave * 32;
+  const int nt = (p.tk + 63) >> 6;
+
+  // ---- LDS-DMA sources: this wave stages keys 16 wave .. 16 wave + 15 of every tile (two pieces per tensor) -------------------
+  const unsigned k_rb = (unsigned)p.k_ts * 2u, v_rb = (unsigned)p.v_ts * 2u;  // row pitches in bytes
+  const half_t* kb = p.k + (long)(b / p.kv_bdiv) * p.k_bs + head * D;
+  const half_t* vb = p.v + (long)(b / p.kv_bdiv) * p.v_bs + head * D;
+  const u32x4 rs_k = f3_rsrc(kb, (unsigned)(p.tk - 1) * k_rb + 128u);
+  const u32x4 rs_v0 = f3_rsrc(vb, (unsigned)(p.tk - 1) * v_rb + 128u);
+  const u32x4 rs_v1 = f3_rsrc(vb + p.v2_off, (unsigned)(p.tk - 1) * v_rb + 128u);
+  unsigned ksrc[2], vsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int key_l = 16 * wave + 8 * j + (lane >> 3), pc = lane & 7;
+    ksrc[j] = (unsigned)key_l * k_rb + (unsigned)((pc ^ ((key_l >> 1) & 7)) * 16);
+    vsrc[j] = (unsigned)key_l * v_rb + (unsigned)((pc ^ (((key_l >> 1) & 1) << 2)) * 16);
+  }
+  const unsigned ktile = 64u * k_rb, vtile = 64u * v_rb;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue = [&](int tile, int so) {  // tile -> stage at byte offset so (wave-uniform)
+    const unsigned base = lds0 + (unsigned)so + (unsigned)wave * 2048u;
+    // (the tile advance goes into the VECTOR offset: the range check that zero-fills keys >= tk must see it)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f3_dma(rs_k, ksrc[j] + (unsigned)tile * ktile, base + j * 1024);
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f3_dma(v ? rs_v1 : rs_v0, vsrc[j] + (unsigned)tile * vtile, base + 8192 * (1 + v) + j * 1024);
+  };
+  const half_t* qp = p.q + (long)b * p.q_bs + head * D;
+  const int qrow = min(q0 + r, p.tq - 1);
+  half8_t qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
+  asm volatile("" ::: "memory");
+  F3_FENCE();
+  // tiles 0 .. NS - 2 go out (behind the Q loads: wherever hipcc places those, the counted wait below is on the safe side)
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t) issue(t, t * TILE);
+  F3_FENCE();
+
+  f32x16 ot[NV][2];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ot[v][dt][e] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+  f32x16 sa[2], sb[2];
+  f32x16 zero16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+
+  // lane-constant parts of the fragment addresses inside a stage
+  int kfo[4];  // K operand of k-step s: key row r (+ 32 tt), chunk (2 s + h) ^ swizzle
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kfo[s] = r * 128 + (((2 * s + h) ^ ((r >> 1) & 7)) * 16);
+  const int vq = (lane & 15) >> 2;  // key of this lane inside a 4-key transposed read
+  int vfo[2];  // V^T fragment of output tile dt: key row 4 h + vq (+ 32 tt + 16 s, + 8), 64-byte half dt ^ swizzle
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) vfo[dt] = 8192 + (4 * h + vq) * 128 + (((32 * ((lane >> 4) & 1) + 8 * (lane & 3))) | ((dt ^ ((vq >> 1) & 1)) << 6));
+
+  // ---- prologue: tile 0 landed, S^T of tile 0 --------------------------------------------------------------------------------
+  f3_wait_vm<(NS - 2) * PCS>();
+  F3_BAR();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    sa[t] = zero16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8_t kf = *reinterpret_cast<const half8_t*>(smem + kfo[s] + 4096 * t);
+      sa[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sa[t], 0, 0, 0);
+    }
+  }
+  int o_v = 0, o_k = TILE, o_w = (NS - 1) * TILE;  // stages of tile t (V read), t + 1 (K read), t + NS - 1 (issued)
+
+  // one tile: softmax + P V of the tile whose scores are in `cur`, S^T of the next tile into `nxt`
+  auto body = [&](f32x16(&cur)[2], f32x16(&nxt)[2], const int t) {
+    F3_STAMP(4);
+    // tile t + 1 complete for this wave (tiles t + 2 .. t + NS - 2 may be in flight), then for every wave; the barrier also
+    // retires every wave's reads of the stage about to be refilled (tile t - 1's)
+    f3_wait_vm<(NS - 3) * PCS>();
+    F3_BAR();
+    F3_STAMP(0);
+    issue(t + NS - 1, o_w);
+    F3_FENCE();
+    F3_STAMP(1);
+    const char* Kn = smem + o_k;
+    const char* Vc = smem + o_v;
+    if (__builtin_amdgcn_readfirstlane((t == nt - 1) && (p.tk & 63))) {  // ragged last tile: mask keys >= tk
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (t * 64 + 32 * tt + 8 * (e >> 2) + 4 * h + (e & 3) >= p.tk) cur[tt][e] = -INFINITY;
+    }
+    F3_FENCE();
+    // K fragments of tile t + 1 (on the last iteration: zeros or a stale stage, the scores are never used)
+    half8_t kf[2][4];  // (k-steps 0, 1 now; 2, 3 in the second region: 16 registers less across the row maximum)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) kf[tt][s] = *reinterpret_cast<const half8_t*>(Kn + kfo[s] + 4096 * tt);
+    half8_t pf[2];
+    half8_t vf[3][NV][2];  // three fragment sets: the reads of k-step f + 1 are issued while P V of f - 1 is still to come
+    auto vread = [&](const int f) {  // V^T fragments of k-step f = (tt, s) = (f >> 1, f & 1): two transposing reads each
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* va = Vc + 8192 * v + vfo[dt] + (32 * (f >> 1) + 16 * (f & 1)) * 128;
+          const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)va);
+          const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(va + 8 * 128));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[f % 3][v][dt][e] = (half_t)lo[e];
+            vf[f % 3][v][dt][4 + e] = (half_t)hi[e];
+          }
+        }
+    };
+    vread(0);
+    F3_FENCE();
+    auto smma = [&](const int i) {  // the i-th S^T MFMA of the next tile: (tt, s) = (i & 1, i >> 1)
+      const int tt = i & 1, s_ = i >> 1;
+      nxt[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[tt][s_], qf[s_], s_ == 0 ? zero16 : nxt[tt], 0, 0, 0);
+    };
+    auto pvmma = [&](const int f, const int dt) {  // O^T += V^T P^T, k-step f, output tile dt (both value tensors)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) ot[v][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[f % 3][v][dt], pf[f & 1], ot[v][dt], 0, 0, 0);
+    };
+    // ---- row maximum of tile t with the first S^T MFMAs --------------------------------------------------------------------
+    float mx = fmaxf(cur[0][0], cur[0][1]);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int e = tt ? 0 : 2; e < 16; e += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, cur[tt][e]), cur[tt][e + 1]);
+    smma(0); smma(1); smma(2);
+    if constexpr (NV == 2) smma(3);
+    mx = flash_xhalf_max(mx);
+    // instruction order of this region: one MFMA, then a few vector instructions (hipcc's own order is all MFMAs first)
+    if constexpr (NV == 1) { F3_GRP(6, 0); F3_GRP(6, 0); F3_GRP(6, 0); }
+    else { F3_GRP(4, 0); F3_GRP(5, 0); F3_GRP(4, 0); F3_GRP(5, 0); }
+    F3_STAMP(2);
+    if (__any((mx - mrun) * p.scale_log2 > FLASH_THR)) {  // wave-uniform; always on the first tile (mrun = -inf)
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2);
+      mrun = mnew;
+      lrun *= alpha;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) ot[v][dt][e] *= alpha;
+    }
+    F3_FENCE();
+    const f32x2 sc2 = {p.scale_log2, p.scale_log2}, mc2 = {-mrun * p.scale_log2, -mrun * p.scale_log2};
+#pragma unroll
+    for (int s = 2; s < 4; ++s)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) kf[tt][s] = *reinterpret_cast<const half8_t*>(Kn + kfo[s] + 4096 * tt);
+    // ---- probabilities fragment by fragment (f = k-step (tt, s)): P V of fragment f - 1 and the rest of S^T run under the
+    //      exponentials of fragment f ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int tt = f >> 1, s_ = f & 1;
+      if (f < 3) vread(f + 1);
+      half8_t& pn = pf[f & 1];
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{cur[tt][8 * s_ + j], cur[tt][8 * s_ + j + 1]}, sc2, mc2);
+        x[j] = __builtin_amdgcn_exp2f(a[0]);
+        x[j + 1] = __builtin_amdgcn_exp2f(a[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pn[j] = (half_t)x[j];
+      // row sum from the fp16-rounded probabilities that enter P V (same order as flash_kernel: bit-identical sums)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lrun = __builtin_amdgcn_fdot2(half2_t{pn[2 * j], pn[2 * j + 1]}, half2_t{(half_t)1.f, (half_t)1.f}, lrun, false);
+      if (f == 0) {
+        smma(NV == 1 ? 3 : 4); smma(NV == 1 ? 4 : 5);
+        if constexpr (NV == 2) { smma(6); smma(7); } else smma(5);
+      } else {
+        pvmma(f - 1, 0); pvmma(f - 1, 1);
+        if constexpr (NV == 1) { if (f < 3) smma(5 + f); }
+      }
+    }
+    pvmma(3, 0);
+    pvmma(3, 1);
+    // region order: the transposing reads of the next fragment, then MFMA : 5 vector : 2-3 transcendental, repeated
+    if constexpr (NV == 1) {
+      F3_RD(8); F3_GRP(5, 3); F3_GRP(5, 2); F3_GRP(5, 3);
+      F3_RD(4); F3_GRP(5, 2); F3_GRP(5, 3); F3_GRP(5, 2);
+      F3_RD(4); F3_GRP(5, 3); F3_GRP(5, 2); F3_GRP(5, 3);
+      F3_GRP(5, 2); F3_GRP(5, 3); F3_GRP(5, 2); F3_GRP(5, 2);
+    } else {
+      F3_RD(12); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2);
+      F3_RD(8); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2);
+      F3_RD(8); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2);
+      F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2); F3_GRP(3, 2);
+      F3_GRP(3, 0); F3_GRP(3, 0); F3_GRP(3, 0); F3_GRP(3, 0);
+    }
+    F3_FENCE();
+    F3_STAMP(3);
+    const int o_ = o_v; o_v = o_k;
+    o_k = o_k + TILE == NS * TILE ? 0 : o_k + TILE;
+    o_w = o_;
+  };
+#pragma unroll 1
+  for (int t = 0;; t += 2) {
+    body(sa, sb, t);
+    if (t + 1 >= nt) break;
+    body(sb, sa, t + 1);
+    if (t + 2 >= nt) break;
+  }
+  f3_wait_vm<0>();  // the pieces issued past the last tile (nothing reads them; the LDS must outlive them)
+#ifdef MVOC_F3_STAMPS
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned long long t1_, r1_;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1_), "=s"(r1_)::"memory");
+    for (int i = 0; i < 5; ++i) f3_dbg[i] = f3_acc[i];
+    f3_dbg[5] = t1_ - f3_t0;
+    f3_dbg[7] = r1_ - f3_r0;
+    f3_dbg[6] = (unsigned long long)nt;
+  }
+#endif
+
+  const float ltot = lrun + __shfl_xor(lrun, 32);
+  const float inv = 1.0f / ltot;
   if (q0 + r < p.tq) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       half_t* op = p.out + v * p.o2_off + (long)b * p.o_bs + (long)(q0 + r) * p.o_ts + head * D;
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           half4_t o;
@@ -253,6 +601,11 @@ __global__ __launch_bounds__(256, (D == 64 && NV == 1) ? FLASH_MINW : 1) void fl
     }
   }
 }
+#undef F3_BAR
+#undef F3_FENCE
+#undef F3_GRP
+#undef F3_RD
+#undef F3_STAMP
 
 // ------------------------------------------------------------------------------------------------
 struct TAttnArgs {
@@ -378,6 +731,10 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
 
 }  // namespace
 
+// -1: by key count (default), 0: flash_kernel always, 1: flash3_kernel wherever it applies (head dim 64, no causal mask)
+static std::atomic<int> g_f3_mode{getenv("MVOC_FLASH3") ? atoi(getenv("MVOC_FLASH3")) : -1};
+extern "C" void mvoc_flash_pipelined(int mode) { g_f3_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+
 extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   MVOC_REQUIRE(d && d->q && d->k && d->v && d->out, -1, "flash_attn: null operand");
   MVOC_REQUIRE(d->nbatch > 0 && d->heads > 0 && d->tq > 0 && d->tk > 0, -1, "flash_attn: empty problem");
@@ -402,19 +759,31 @@ extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "flash_attn: grid too large");
   dim3 grid((unsigned)nblk);
   a.v2_off = a.o2_off = 0;
+  // long key rows of the UNet's self-attention: the software-pipelined kernel (same results bit for bit; +1.5-4 % from 3 600 keys
+  // up, -3 % at 1 024: same-box A/B, profiles/r4/flash3_ab.txt); mvoc_flash_pipelined() / MVOC_FLASH3=0 / 1 force one kernel
+  const int f3_mode = g_f3_mode.load(std::memory_order_relaxed);
+  const bool pipelined = hd == 64 && !d->causal && (f3_mode >= 0 ? f3_mode != 0 : d->tk >= 2048);
   if (d->v2) {
     MVOC_REQUIRE(d->out2 && hd == 64, -2, "flash_attn: the paired form needs out2 and head_dim 64");
     a.v2_off = (const half_t*)d->v2 - a.v;
     a.o2_off = (half_t*)d->out2 - a.out;
     MVOC_REQUIRE(a.v2_off % 8 == 0 && a.o2_off % 4 == 0, -2, "flash_attn: v2 / out2 must keep 16-byte alignment");
-    hipLaunchKernelGGL((flash_kernel<64, 2>), grid, dim3(256), 0, s, a);
+    if (pipelined) hipLaunchKernelGGL((flash3_kernel<2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flash_kernel<64, 2>), grid, dim3(256), 0, s, a);
   } else if (hd == 64) {
-    hipLaunchKernelGGL((flash_kernel<64, 1>), grid, dim3(256), 0, s, a);
+    if (pipelined) hipLaunchKernelGGL((flash3_kernel<1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flash_kernel<64, 1>), grid, dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL((flash_kernel<96, 1>), grid, dim3(256), 0, s, a);
   }
   return mvoc_check_launch("flash_kernel");
 }
+
+#ifdef MVOC_F3_STAMPS
+extern "C" int mvoc_f3_stamps_read(unsigned long long* host8) {
+  return hipMemcpyFromSymbol(host8, HIP_SYMBOL(f3_dbg), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int mvoc_temporal_attn_f16(const mvoc_tattn_desc* d, void* stream) {
   MVOC_REQUIRE(d && d->q && d->k && d->v && d->out, -1, "temporal_attn: null operand");

@@ -184,6 +184,11 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     return out
 
 
+def flash_pipelined(mode):
+    """kernel choice behind flash_attn (include/mvoc_hip.h: mvoc_flash_pipelined): -1 by key count, 0 / 1 force; same bits either way"""
+    lib.mvoc_flash_pipelined(int(mode))
+
+
 def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=64, causal=False, scale=0.0, v2=None, out2=None):
     """softmax(q k^T * scale) v.  q [nbatch*tq, >=heads*head_dim] / k, v [(nbatch/kv_bdiv)*tk, ..] row-major views.
     head_dim 64 (scale 1/8) is the UNet's; 96 + an explicit scale + ``causal`` serve the CLIP towers (clip.py).

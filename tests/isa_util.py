@@ -92,6 +92,12 @@ def loops(ins):
 
 def main_loop(ins):
     """the loop with the most MFMAs among the loops that contain no other MFMA-carrying loop (the K loop / stage loop)"""
+    a, b = main_loop_bounds(ins)
+    return ins[a:b + 1]
+
+
+def main_loop_bounds(ins):
+    """(first index, last index) of main_loop"""
     ls = loops(ins)
     best, best_n = None, -1
     for a, b in ls:
@@ -100,4 +106,4 @@ def main_loop(ins):
         if n > best_n and not inner:
             best, best_n = (a, b), n
     assert best is not None, "no MFMA loop"
-    return ins[best[0]:best[1] + 1]
+    return best

@@ -1,4 +1,5 @@
-"""ISA-level guard for the hand-counted `s_waitcnt vmcnt(N)` of the LDS-DMA rings (gemm8.hip, xslin.hip, tfused.hip).
+"""ISA-level guard for the hand-counted `s_waitcnt vmcnt(N)` of the LDS-DMA rings (gemm8.hip, xslin.hip, tfused.hip, attention.hip's
+flash3_kernel).
 
 Those kernels keep LDS-DMA in flight across raw `s_barrier`s and retire it with COUNTED waits: gfx950's vmcnt counts every
 vector-memory instruction of a wave (loads, stores, LDS-DMA) in issue order, so a wait is right only while the number of such
@@ -26,7 +27,7 @@ CSRC = os.path.join(REPO, "mvoc_amd", "csrc")
 def objs():
     from mvoc_amd import build
     build.build(verbose=False)
-    return {f: I.disassemble(os.path.join(CSRC, f + ".o")) for f in ("gemm8", "xslin", "tfused")}
+    return {f: I.disassemble(os.path.join(CSRC, f + ".o")) for f in ("gemm8", "xslin", "tfused", "attention")}
 
 
 def _targs(name):
@@ -115,6 +116,32 @@ def test_tfused_ring_has_no_ordinary_loads(objs):
         waits = {i.vmcnt() for i in ins if i.vmcnt() is not None}
         if nw == 4 and nk % nw == 0:                   # the exact steady-state forms: pieces + {2, 4} output stores behind them
             assert {pw + 2, pw + 4} <= waits, (key, sorted(waits))
+
+
+def test_flash3_ring_waits_match_the_pieces_issued(objs):
+    """attention.hip flash3_kernel<NV>: per key tile a wave issues 2 K + 2 NV V pieces (asm statements: hipcc does not see them,
+    so EVERY vmcnt wait of the loop is the kernel's own) into a ring of three stages; the wait at the top of an iteration leaves
+    (stages - 3) tiles in flight.  The loop holds two tiles (the score accumulators swap roles statically)."""
+    ks = {_targs(n)[0]: v for n, v in objs["attention"].items() if "flash3_kernel" in n}
+    assert set(ks) == {1, 2}
+    for nv, ins in ks.items():
+        pcs = 2 + 2 * nv
+        a, b = I.main_loop_bounds(ins)
+        loop = ins[a:b + 1]
+        assert sum(1 for i in loop if i.is_mfma) == 2 * (8 + 8 * nv), nv
+        assert sum(1 for i in loop if i.is_lds_dma) == 2 * pcs, nv
+        assert [i.op for i in loop if i.is_vmem and not i.is_lds_dma] == [], (nv, "an ordinary vector-memory instruction inside the ring loop")
+        waits = [i.vmcnt() for i in loop if i.vmcnt() is not None]
+        assert waits == [0, 0], (nv, waits)  # three stages: tile t + 1 is the newest in flight at the top of iteration t
+        # prologue: two tiles out, the first one complete -> one tile's pieces may remain; every LDS-DMA has M0 written just ahead
+        pro = ins[:a]
+        assert sum(1 for i in pro if i.is_lds_dma) == 2 * pcs, nv
+        assert pcs in [i.vmcnt() for i in pro if i.vmcnt() is not None], nv
+        for j, i in enumerate(ins):
+            if i.is_lds_dma:
+                assert ins[j - 2].op == "s_mov_b32" and ins[j - 2].args.startswith("m0,") and ins[j - 1].op == "s_nop", (nv, hex(i.addr))
+        # the epilogue drains the pieces issued past the last tile before the block's LDS is released
+        assert 0 in [i.vmcnt() for i in ins[b + 1:] if i.vmcnt() is not None], nv
 
 
 def test_no_waterfall_loop_wraps_a_dma(objs):

@@ -406,8 +406,18 @@ def test_geglu_layernorm_fold_production(ops, m, c, inner, tile):
 
 
 # ---- attention ----------------------------------------------------------------------------------------
+@pytest.fixture(params=[0, 1], ids=["flash_kernel", "flash3_kernel"])
+def fmode(request, ops):
+    """every flash-attention test runs through BOTH kernels behind mvoc_flash_attn_f16 (attention.hip: the phase kernel and the
+    software-pipelined LDS-DMA kernel; by default the key count picks one, and most test shapes are below the switch point).
+    head_dim 96 / causal calls ignore the switch."""
+    ops.flash_pipelined(request.param)
+    yield request.param
+    ops.flash_pipelined(-1)
+
+
 @pytest.mark.parametrize("tq,tk,heads,kv_bdiv", [(256, 256, 2, 1), (100, 100, 1, 1), (200, 145, 2, 3), (64, 64, 5, 1), (130, 77, 1, 1)])
-def test_flash_attn(ops, tq, tk, heads, kv_bdiv):
+def test_flash_attn(ops, fmode, tq, tk, heads, kv_bdiv):
     g = torch.Generator().manual_seed(tq + tk)
     nb = 6
     c = heads * 64
@@ -426,7 +436,7 @@ def test_flash_attn(ops, tq, tk, heads, kv_bdiv):
 
 @pytest.mark.parametrize("tq,tk,heads,kv_bdiv,nb", [(1024, 1024, 5, 1, 3), (300, 512, 2, 2, 4), (256, 256, 1, 1, 2), (4096, 4096, 1, 1, 1),
                                                      (920, 960, 2, 1, 2), (2100, 192, 1, 1, 1)])
-def test_flash_attn_eight_wave(ops, tq, tk, heads, kv_bdiv, nb):
+def test_flash_attn_eight_wave(ops, fmode, tq, tk, heads, kv_bdiv, nb):
     """many KV tiles (3 / 4 / 8 / 15 / 16 / 64), query counts that leave waves of the last block without rows, shared K/V across
     batch entries, strided q/k/v views of a fused QKV buffer (written for the eight-wave laboratory kernel of round 3,
     tools/lab/flash2_kernel.hip.inc; kept as coverage of the production kernel at the network's real token counts)"""
@@ -444,7 +454,7 @@ def test_flash_attn_eight_wave(ops, tq, tk, heads, kv_bdiv, nb):
     assert (out.float().cpu() - ref).abs().max() < 1e-2
 
 
-def test_flash_attn_eight_wave_large_scores(ops):
+def test_flash_attn_eight_wave_large_scores(ops, fmode):
     """spiked keys in different KV tiles force running-max jumps (the online-softmax rescale branch); an exact-integer value
     matrix makes a wrong V fragment map (transposed LDS read) show as a wrong integer"""
     g = torch.Generator().manual_seed(5)
@@ -470,7 +480,7 @@ def test_flash_attn_eight_wave_large_scores(ops):
     assert torch.equal(out.float().cpu(), vi.float())
 
 
-def test_flash_attn_large_scores(ops):
+def test_flash_attn_large_scores(ops, fmode):
     """spiked keys force big running-max jumps between KV tiles (online-softmax rescale path)"""
     g = torch.Generator().manual_seed(3)
     nb, t, heads = 1, 320, 1
@@ -485,7 +495,7 @@ def test_flash_attn_large_scores(ops):
     assert (out.float().cpu() - ref).abs().max() < 1e-2
 
 
-def test_flash_attn_deferred_max(ops):
+def test_flash_attn_deferred_max(ops, fmode):
     """the running maximum is rescaled only when it grew by more than 2^8 (attention.hip: FLASH_THR): keys that lift a row's
     maximum by LESS than the threshold in late tiles leave P > 1 against the stale maximum -- checked against an fp64 softmax
     for growth just below, at and above the threshold, in the first and in later tiles"""
@@ -506,7 +516,7 @@ def test_flash_attn_deferred_max(ops):
 
 
 @pytest.mark.parametrize("t,heads,nb", [(256, 2, 3), (1000, 5, 2), (4096, 1, 1)])
-def test_flash_attn_pair_equals_two_calls(ops, t, heads, nb):
+def test_flash_attn_pair_equals_two_calls(ops, fmode, t, heads, nb):
     """PnP destination pair (pnp_utils.py:664-668: one blended q / k for the unconditional and the conditional chunk): the paired
     launch (v2 / out2) returns, bit for bit, what two plain launches with the same q / k return"""
     g = torch.Generator().manual_seed(t + heads)
@@ -522,6 +532,36 @@ def test_flash_attn_pair_equals_two_calls(ops, t, heads, nb):
     q4, k4 = (x[:half].float().cpu().reshape(nb, t, heads, 64).transpose(1, 2) for x in (q, k))
     v4 = v[half:].float().cpu().reshape(nb, t, heads, 64).transpose(1, 2)
     assert rel_l2(out[half:], F.scaled_dot_product_attention(q4, k4, v4).transpose(1, 2).reshape(half, c)) < 2e-3
+
+
+@pytest.mark.parametrize("nb,heads,tq,tk,kv_bdiv,pair", [(2, 5, 4096, 4096, 1, 0), (2, 2, 920, 920, 1, 0), (2, 3, 1024, 1024, 1, 1), (4, 2, 300, 145, 2, 0),
+                                                         (1, 1, 130, 64, 1, 0), (1, 2, 2100, 2240, 1, 1), (2, 1, 129, 3600, 1, 0), (2, 2, 50, 129, 1, 1)])
+def test_flash_attn_kernels_agree_bitwise(ops, nb, heads, tq, tk, kv_bdiv, pair):
+    """flash3_kernel (software-pipelined, LDS-DMA ring behind hand-counted waits) against flash_kernel on the same inputs: same
+    fragment maps, rounding points and summation order, so every output bit must agree -- 1 to 64 key tiles, ragged last tiles
+    (keys past tk are zero-filled by the buffer range check and masked), query blocks with idle waves, shared K/V, the pair form,
+    strided views of a fused QKV buffer.  A miscounted wait or a wrong swizzle shows here as a differing bit."""
+    g = torch.Generator().manual_seed(nb * 1000 + tq + tk)
+    c = heads * 64
+    q = dev((1.5 * torch.randn(nb * tq, 3 * c, generator=g)).half())[:, c:2 * c]
+    kv = dev((1.2 * torch.randn((nb // kv_bdiv) * tk, 3 * c, generator=g)).half())
+    k, v, v2 = kv[:, :c], kv[:, c:2 * c], kv[:, 2 * c:]
+    outs = []
+    for mode in (0, 1):
+        ops.flash_pipelined(mode)
+        try:
+            o = torch.full((nb * tq, c), float("nan"), dtype=torch.float16, device=q.device)
+            o2 = torch.full((nb * tq, c), float("nan"), dtype=torch.float16, device=q.device)
+            if pair:
+                ops.flash_attn(q, k, v, nbatch=nb, heads=heads, tq=tq, tk=tk, kv_bdiv=kv_bdiv, out=o, v2=v2, out2=o2)
+            else:
+                ops.flash_attn(q, k, v, nbatch=nb, heads=heads, tq=tq, tk=tk, kv_bdiv=kv_bdiv, out=o)
+                o2.zero_()
+            outs.append((o.cpu(), o2.cpu()))
+        finally:
+            ops.flash_pipelined(-1)
+    assert not torch.isnan(outs[0][0]).any() and not torch.isnan(outs[0][1]).any()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize("frames,heads", [(16, 2), (3, 1), (32, 1), (8, 5)])
