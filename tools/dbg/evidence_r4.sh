@@ -21,6 +21,7 @@ python tools/gemm_bench.py 1 0 > $OUT/gemm_per_shape_B1.txt 2>&1
 python tools/gemm_bench.py 5 0 > $OUT/gemm_per_shape_B5.txt 2>&1
 python tools/attn_bench.py 5 > $OUT/attn_bench_B5.txt 2>&1
 python tools/attn_bench.py 1 > $OUT/attn_bench_B1.txt 2>&1
+for v in 0 1 0 1; do echo "MVOC_FLASH3=$v (0: flash_kernel, 1: flash3_kernel)"; MVOC_FLASH3=$v python tools/dbg/attn_big.py 2>&1 | grep "^nb"; done > $OUT/attn_long_rows_both_kernels.txt
 python tools/lab/streams_ab.py > $OUT/inversion_three_streams_experiment.txt 2>&1
 bash tools/dbg/clock_run.sh $OUT > /dev/null 2>&1
 python bench.py --latent-h 90 --latent-w 160 --no-cpu-baseline > $OUT/bench_latent_90x160.json 2> /dev/null
