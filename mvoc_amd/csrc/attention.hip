@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256, NV == 1 ? F3_W1 : 2) void flash3_kernel(const 
   half8_t qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + (long)qrow * p.q_ts + 16 * s + 8 * h);
-  asm volatile("" ::: "memory");
+  // (the resource words come from v_readfirstlane: a vector-written SGPR needs five wait states before a buffer instruction reads
+  // it as its descriptor, and hipcc pads nothing inside an asm statement)
+  asm volatile("s_nop 4" ::: "memory");
   F3_FENCE();
   // tiles 0 .. NS - 2 go out (behind the Q loads: wherever hipcc places those, the counted wait below is on the safe side)
 #pragma unroll
