@@ -29,6 +29,7 @@ struct GnArgs {
   int nsample, R, c, c1, c2, G, cpg, silu;
   int nchunk, rows_per_chunk;
   int CW, RY, npass;
+  int aCW, aRY, anpass;  // gn_apply's own thread geometry (no LDS limit on rows per block: all 256 threads get a channel chunk)
   float eps;
 };
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void gn_merge_parts(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
   const int tid = threadIdx.x;
-  const int cx = tid % p.CW, ry = tid / p.CW;
+  const int cx = tid % p.aCW, ry = tid / p.aCW;
   const int smp = blockIdx.y, chunk = blockIdx.x;
   const int r0 = chunk * p.rows_per_chunk;
   const int r1 = min(r0 + p.rows_per_chunk, p.R);
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
     __syncthreads();
     fin = lfin;
   }
-  if (ry >= p.RY) return;
-  for (int pass = 0; pass < p.npass; ++pass) {
-    const int cc = pass * p.CW + cx;
+  if (ry >= p.aRY) return;
+  for (int pass = 0; pass < p.anpass; ++pass) {
+    const int cc = pass * p.aCW + cx;
     if (cc * 8 >= p.c) continue;
     float sc[8], sh[8];
     const half8_t gm = *reinterpret_cast<const half8_t*>(p.gamma + cc * 8);
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
       sh[e] = (float)bt[e] - mean * sc[e];
     }
     int rr = r0 + ry;
-    for (; rr + 3 * p.RY < r1; rr += 4 * p.RY) {  // four loads in flight per thread
+    for (; rr + 3 * p.aRY < r1; rr += 4 * p.aRY) {  // four loads in flight per thread
       half8_t v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.RY, cc * 8));
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.aRY, cc * 8));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         half8_t o;
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
           if (p.silu) y = silu_f(y);
           o[e] = (half_t)y;
         }
-        *reinterpret_cast<half8_t*>(p.out + (rowbase + rr + u * p.RY) * p.c + cc * 8) = o;
+        *reinterpret_cast<half8_t*>(p.out + (rowbase + rr + u * p.aRY) * p.c + cc * 8) = o;
       }
     }
-    for (; rr < r1; rr += p.RY) {
+    for (; rr < r1; rr += p.aRY) {
       const half8_t v = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr, cc * 8));
       half8_t o;
 #pragma unroll
@@ -306,6 +307,10 @@ void gn_geometry(GnArgs& a) {
   a.CW = cchunks < 256 ? cchunks : 256;
   a.RY = 256 / a.CW;
   a.npass = (cchunks + a.CW - 1) / a.CW;
+  // gn_apply walks the same geometry.  (Its own, with all 256 threads busy -- 1 280 channels as 80 chunks x 3 rows in two passes
+  // instead of 160 x 1 with 96 idle threads -- was SLOWER: 37.1 against 31.8 us at 20 480 x 1 280, whole 2 560-byte rows per
+  // thread-row beat two passes over 1 280-byte halves.)
+  a.aCW = a.CW; a.aRY = a.RY; a.anpass = a.npass;
   int want = 2048 / (a.nsample > 0 ? a.nsample : 1);
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
@@ -535,7 +540,11 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
     a.sums = (const float*)d->chan_sums;
     a.sums2 = (const float*)d->chan_sums2;
     a.nslab = d->rows_per_sample / 256;
-    a.inline_final = a.nslab <= 16 && 256 % a.G == 0;
+    // every block of the sample re-reads the sample's sums (nslab x C x 8 bytes, out of L2): worth a launch less only while that
+    // is small beside the rows a block streams -- 16 slabs x 1 280 channels = 164 KB per block against ~25 KB of rows was a loss
+    // (tools/dbg/gn_bench.py: 47.9 us against 41.1 with its own statistics pass at B = 5)
+    static const long inline_max = getenv("MVOC_GN_INLINE_BYTES") ? atol(getenv("MVOC_GN_INLINE_BYTES")) : 49152;
+    a.inline_final = (long)a.nslab * a.c * 8 <= inline_max && a.nslab <= 16 && 256 % a.G == 0;
   } else {
     hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
   }
