@@ -85,11 +85,25 @@ typedef struct mvoc_gemm_desc {
                            launch runs on the eight-phase tiles without split-K and without activation: ask
                            mvoc_gemm_chan_sums_written() after the call; when it answers 0 the buffer is untouched and the
                            consumer computes its own statistics (mvoc_groupnorm_f16 without chan_sums). */
+  void* row_moments;    /* optional REQUEST, fp32 [m][row_moments_ld][2]: per output ROW and n-tile of the launch, the sum and the sum of
+                           squares of the values this call stores over the tile's channels -- the statistics of the LayerNorm that
+                           reads `out` next (F.layer_norm at pnp_utils.py:250-257, 296, 322), taken from the producer's epilogue
+                           instead of a pass over the tensor (mvoc_row_stats_f16).  Written only by the eight-phase tiles without
+                           split-K and with n_store == n: ask mvoc_gemm_row_moments_written() after the call -- 0: untouched;
+                           otherwise the tile width w (256 or 320): entry [r][t] covers channels [t w, min(n, (t + 1) w)), and
+                           mvoc_row_stats_from_moments_f32 turns the entries of a row into its {mean, rstd}. */
+  int32_t row_moments_ld; /* entries per row of row_moments: >= ceil(n / 256) */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
 /* 1 when this thread's most recent mvoc_gemm_f16 call wrote its descriptor's chan_sums */
 int mvoc_gemm_chan_sums_written(void);
+/* tile width (256 / 320) when this thread's most recent mvoc_gemm_f16 call wrote its descriptor's row_moments, else 0 */
+int mvoc_gemm_row_moments_written(void);
+/* {mean, rstd} per row (fp32 [rows][2], the layout of mvoc_row_stats_f16 / ln_stats) from a producer's row_moments: the n-tiles'
+ * {sum, sum of squares} become {count, mean, M2} per tile and are Chan-merged in tile order. */
+int mvoc_row_stats_from_moments_f32(const void* moments, int64_t rows, int32_t ld, int32_t n, int32_t tile_w, float eps,
+                                    void* out_stats, void* stream);
 /* Scheduling hint for the tile / split-K choice of the calls that follow: the caller runs n independent launches of each shape at
  * the same time on n streams (the job's per-object inversions, inverse.py:136-190 as concurrent loops), so an under-filled grid
  * need not be split over K to fill the chip.  Process-wide, returns the previous value; 1 (the default) = alone.  Affects speed

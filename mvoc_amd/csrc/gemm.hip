@@ -812,9 +812,11 @@ namespace {
 // the other clips' blocks take the idle CUs.  1 = the launch has the chip to itself.
 int g_conc = 1;
 thread_local int g_sums_written = 0;
+thread_local int g_rowmom_bx = 0;
 const bool g_trace = getenv("MVOC_GEMM_TRACE") != nullptr;  // diagnostics: one line per launch with the dispatch decision
 }
 extern "C" int mvoc_gemm_chan_sums_written(void) { return g_sums_written; }
+extern "C" int mvoc_gemm_row_moments_written(void) { return g_rowmom_bx; }
 extern "C" int mvoc_gemm_concurrency_hint(int n) {
   const int old = g_conc;
   g_conc = n < 1 ? 1 : (n > 8 ? 8 : n);
@@ -823,6 +825,7 @@ extern "C" int mvoc_gemm_concurrency_hint(int n) {
 
 extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   g_sums_written = 0;
+  g_rowmom_bx = 0;
   MVOC_REQUIRE(d && d->a && d->w && d->out, -1, "gemm: null operand");
   MVOC_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, -1, "gemm: empty problem m=%ld n=%ld k=%ld", (long)d->m, (long)d->n,
                (long)d->k);
@@ -1011,7 +1014,14 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
         a.stats = (float*)d->chan_sums;
         g_sums_written = 1;
       }
-      const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : 320, s);
+      if (d->row_moments && a.split_k == 1 && d->act != MVOC_ACT_GEGLU && a.n_store == a.N) {  // LayerNorm statistics likewise
+        MVOC_REQUIRE(d->row_moments_ld >= (a.N + 255) / 256, -2, "gemm: row_moments_ld %d < ceil(n / 256)", d->row_moments_ld);
+        a.rowmom = (float*)d->row_moments;
+        a.rowmom_ld = d->row_moments_ld;
+      }
+      int bx_used = 0;
+      const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : 320, s, &bx_used);
+      if (rc == 0 && a.rowmom) g_rowmom_bx = bx_used;
       if (rc == 0 && a.split_k > 1) {
         const long nthr = (long)a.M * (a.N / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);

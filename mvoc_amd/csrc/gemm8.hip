@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       // per pass against 4-5 k with plain stores (launch 230 -> 218 us at K = 960, 288 -> 262 with a residual); the 256-wide
       // tile with plain stores loses 15 % instead (its stores then evict operand lines: 2 734 -> 3 242 ticks per K tile)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, chunk_off(a, lane2, it, p.ldo), 0, (G8_NT_STORE && XT == 4) ? 2 : 0);
-      if (p.stats && it < nchunk) *reinterpret_cast<half8_t*>(epi + px * PITCH + c * 16) = v;  // the STORED values, for stats_pass
+      if ((p.stats || p.rowmom) && it < nchunk) *reinterpret_cast<half8_t*>(epi + px * PITCH + c * 16) = v;  // the STORED values, for stats_pass / rowmom_pass
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next pass overwrites the tile
   };
@@ -659,6 +659,35 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       if (kg == (n >> 2)) *reinterpret_cast<float2*>(so + (cb * 16 + n) * 2) = float2{dsum[0], sq};
     }
   };
+  // Per-ROW sum and sum of squares of the values just stored, over this wave's XQ channels of the pass (what the consumer's
+  // LayerNorm reads: pnp_utils.py:250-257, 296, 322), the same way: with ROW-major fragments of the tile (pixel on the lane, 8
+  // channels per lane: plain 16-byte LDS reads) as both operands, D = X X^T is the Gram matrix of a 16-pixel block -- its diagonal
+  // the rows' sums of squares -- and ones x X^T the row sums.  The four (channel half, pass) quarters of a row meet in LDS and
+  // leave as ONE {sum, sum of squares} per row and n-tile; the consumer's statistics come from merging a row's n-tiles
+  // (mvoc_row_stats_from_moments_f32) instead of a pass over the tensor (row_stats_kernel: 1.4 % of GPU time).
+  constexpr int R_OFF = S_OFF + 4 * BX * 8;  // fp32 [quarter][256 rows][2]
+  static_assert(R_OFF + 4 * 256 * 8 <= SMEM, "row-moment area");
+  auto rowmom_pass = [&](int a) {
+    const half8_t ones = {(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+    const half8_t zero8 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    const int kg = lane >> 4, n = lane & 15;
+    float* ro = reinterpret_cast<float*>(smem + R_OFF) + ((wr * 2 + a) * 256 + wc * 64) * 2;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      f32x4 dg = {0.f, 0.f, 0.f, 0.f}, dsum = dg;
+#pragma unroll
+      for (int ks = 0; ks * 32 < XQ; ++ks) {
+        // lane (pixel n of the block, channel group kg): channels 32 ks + 8 kg .. + 7 (320-wide: the third step holds 16 channels)
+        half8_t f = zero8;
+        if (ks * 32 + kg * 8 < XQ) f = *reinterpret_cast<const half8_t*>(epi + (rb * 16 + n) * PITCH + (ks * 32 + kg * 8) * 2);
+        dg = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, f, dg, 0, 0, 0);
+        dsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, f, dsum, 0, 0, 0);
+      }
+      // D[m][n] sits in lane (n, m >> 2), register m & 3: the diagonal element of pixel n in the lane whose group is n >> 2
+      const float sq = (n & 3) == 0 ? dg[0] : (n & 3) == 1 ? dg[1] : (n & 3) == 2 ? dg[2] : dg[3];
+      if (kg == (n >> 2)) *reinterpret_cast<float2*>(ro + (rb * 16 + n) * 2) = float2{dsum[0], sq};
+    }
+  };
   {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -679,21 +708,35 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     if constexpr (XT != 4) load_resid(1, r1, R1_EARLY, XT * 2);
     __builtin_amdgcn_sched_barrier(0);
     if (p.stats) stats_pass(0);
+    if (p.rowmom) rowmom_pass(0);
     __builtin_amdgcn_sched_barrier(0);
     arith(I1{});
     __builtin_amdgcn_sched_barrier(0);
     readback_store(1, r1);
     G8_STAMP(4);
-    if (p.stats) {
-      stats_pass(1);
+    if (p.stats || p.rowmom) {
+      if (p.stats) stats_pass(1);
+      if (p.rowmom) rowmom_pass(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       G8_BAR();
-      // the four pixel quarters of the tile, summed in a fixed order: [m tile][n_store][2] fp32, coalesced
-      for (int i = tid; i < BX * 2; i += 512) {
-        const int ch = i >> 1;
-        if (n0 + ch < p.n_store) {
-          const float* si = reinterpret_cast<const float*>(smem + S_OFF) + i;
-          p.stats[((size_t)(m0 >> 8) * p.n_store + n0) * 2 + i] = ((si[0] + si[BX * 2]) + si[2 * BX * 2]) + si[3 * BX * 2];
+      if (p.stats) {
+        // the four pixel quarters of the tile, summed in a fixed order: [m tile][n_store][2] fp32, coalesced
+        for (int i = tid; i < BX * 2; i += 512) {
+          const int ch = i >> 1;
+          if (n0 + ch < p.n_store) {
+            const float* si = reinterpret_cast<const float*>(smem + S_OFF) + i;
+            p.stats[((size_t)(m0 >> 8) * p.n_store + n0) * 2 + i] = ((si[0] + si[BX * 2]) + si[2 * BX * 2]) + si[3 * BX * 2];
+          }
+        }
+      }
+      if (p.rowmom) {
+        // the four channel quarters of a row, summed in a fixed order: [row][n tile][2] fp32
+        for (int i = tid; i < 256 * 2; i += 512) {
+          const int row = m0 + (i >> 1);
+          if (row < p.M) {
+            const float* ri = reinterpret_cast<const float*>(smem + R_OFF) + i;
+            p.rowmom[((size_t)row * p.rowmom_ld + ntile) * 2 + (i & 1)] = ((ri[0] + ri[512]) + ri[1024]) + ri[1536];
+          }
         }
       }
     }
@@ -753,7 +796,10 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
 // bx = 256 or 320 output channels per block.  Preconditions (checked by the caller, gemm.hip): k, cin, c1 multiples of 64,
 // conv k == 9 cin, 16-byte addressable outputs (epi_lds), row statistics precomputed when a LayerNorm is folded in, GEGLU
 // only with bx = 256, every operand spanning < 2 GB (32-bit MUBUF offsets).
-int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
+int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s, int* bx_used) {
+  int dummy;
+  int& used = bx_used ? *bx_used : dummy;
+  used = 256;
   if (a.upsample) {  // (rare: the three upsampler convs of a forward) one form serves every width
     if (bx == 256 || bx == 320) return launch8<4, true, true, true, false>(a, s);
   } else {
@@ -763,6 +809,7 @@ int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s) {
       // the 320-wide tile exists for the epilogue forms without activation; anything else (never on a 320-wide shape of this
       // model) takes the 256-wide tile, which holds every form
       if (a.act != MVOC_ACT_NONE || (a.ln_s && a.rowadd)) return launch8<4, true, true, false, false>(a, s);
+      used = 320;
       return launch8<5, false, false, false, true>(a, s);
     }
   }

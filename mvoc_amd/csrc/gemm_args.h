@@ -32,9 +32,11 @@ struct GemmArgs {
   int sh_nt, sh_sk, sh_hwout, sh_wout, sh_hw, sh_fr, sh_ra, sh_band;
   int band;  // gemm8 tile order: m-tiles per band (gemm8.hip)
   float* stats;  // gemm8, optional: per 256-row tile and output channel {sum, sum of squares} of the stored values, fp32 [m_tiles][n_store][2]
+  float* rowmom;  // gemm8, optional: per output row and n-tile {sum, sum of squares} of the stored values, fp32 [M][rowmom_ld][2]
+  int rowmom_ld;
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 
 
 // eight-phase kernel (gemm8.hip): bx = 256 or 320 output channels per block, 256 pixels per block
-int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s);
+int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s, int* bx_used = nullptr);  // *bx_used: the tile width that ran

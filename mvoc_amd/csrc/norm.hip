@@ -471,6 +471,43 @@ extern "C" int mvoc_row_stats_f16(const void* x, void* stats, int64_t rows, int3
   return mvoc_check_launch("row_stats_kernel");
 }
 
+namespace {
+// {sum, sum of squares} of a row's n-tiles (a GEMM epilogue's row_moments) -> the row's {mean, rstd}: per tile {count, mean, M2},
+// Chan-merged in tile order (the sum of squares of a tile is a sum of exact fp32 products; the subtraction happens per tile of
+// <= 320 channels, the tiles meet through their means)
+__global__ __launch_bounds__(256) void row_stats_from_moments_kernel(const float* __restrict__ mom, float* __restrict__ stats, long rows,
+                                                                     int ld, int n, int tile_w, float eps) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float2* in = reinterpret_cast<const float2*>(mom) + r * ld;
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int t = 0; t * tile_w < n; ++t) {
+    const float2 v = in[t];
+    const float nb = (float)min(tile_w, n - t * tile_w);
+    const float mb = v.x / nb;
+    const float m2b = fmaxf(v.y - v.x * mb, 0.f);
+    const float nt = cnt + nb, delta = mb - mean;
+    mean += delta * (nb / nt);
+    m2 += m2b + delta * delta * (cnt * nb / nt);
+    cnt = nt;
+  }
+  reinterpret_cast<float2*>(stats)[r] = float2{mean, rsqrtf(m2 / cnt + eps)};
+}
+}  // namespace
+
+extern "C" int mvoc_row_stats_from_moments_f32(const void* moments, int64_t rows, int32_t ld, int32_t n, int32_t tile_w, float eps,
+                                               void* out_stats, void* stream) {
+  MVOC_REQUIRE(moments && out_stats && rows > 0 && n > 0 && (tile_w == 256 || tile_w == 320) && ld >= (n + tile_w - 1) / tile_w, -1,
+               "row_stats_from_moments: bad args (tile_w 256 | 320, ld >= ceil(n / tile_w))");
+  hipStream_t s = (hipStream_t)stream;
+  MvocProfScope prof(MVOC_FAM_LN, s, (double)rows * (8.0 * ((n + tile_w - 1) / tile_w) + 8.0));
+  const long nblk = (rows + 255) / 256;
+  MVOC_REQUIRE(nblk < 0x7fffffffL, -2, "row_stats_from_moments: too many rows");
+  hipLaunchKernelGGL(row_stats_from_moments_kernel, dim3((unsigned)nblk), dim3(256), 0, s, (const float*)moments, (float*)out_stats,
+                     (long)rows, ld, n, tile_w, eps);
+  return mvoc_check_launch("row_stats_from_moments_kernel");
+}
+
 extern "C" size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups) {
   GnArgs a;
   memset(&a, 0, sizeof(a));

@@ -42,7 +42,10 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
-def _gemm(d: GemmDesc, dev=None, out=None, sums=False):
+USE_ROW_MOMENTS = os.environ.get("MVOC_ROW_MOMENTS", "1") != "0"  # LayerNorm statistics from the producing GEMM's epilogue
+
+
+def _gemm(d: GemmDesc, dev=None, out=None, sums=False, rowmom=False):
     # problems with few output tiles and a deep K get a scratch for deterministic split-K (see gemm.hip)
     if dev is not None and d.act != ACT_GEGLU and d.split_k != 1:
         nbytes = lib.mvoc_gemm_workspace_bytes(d.m, d.n, d.k)
@@ -54,9 +57,19 @@ def _gemm(d: GemmDesc, dev=None, out=None, sums=False):
         # REQUEST for the producer-epilogue GroupNorm statistics (include/mvoc_hip.h: chan_sums); honoured by the eight-phase tiles
         cs = torch.empty((d.m // 256, out.shape[1], 2), dtype=torch.float32, device=out.device)
         d.chan_sums = cs.data_ptr()
+    rm = None
+    if rowmom and USE_ROW_MOMENTS and out is not None and d.act != ACT_GEGLU and out.is_contiguous() and out.shape[1] == d.n:
+        # REQUEST for the producer-epilogue LayerNorm statistics (include/mvoc_hip.h: row_moments); honoured by the eight-phase tiles
+        ld = (d.n + 255) // 256
+        rm = torch.empty((d.m, ld, 2), dtype=torch.float32, device=out.device)
+        d.row_moments, d.row_moments_ld = rm.data_ptr(), ld
     check(lib.mvoc_gemm_f16(C.byref(d), _stream()), "gemm")
     if cs is not None and lib.mvoc_gemm_chan_sums_written():
         out.chan_sums = cs  # rides on the tensor OBJECT: a view / slice / copy of it carries no statistics
+    if rm is not None:
+        w_ = lib.mvoc_gemm_row_moments_written()
+        if w_:
+            out.row_moments = (rm, w_)  # likewise: (fp32 [m][ld][2], tile width)
 
 
 class gemm_concurrency:
@@ -105,9 +118,10 @@ def _out_cols(w, n_store, act):
 
 
 def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out=None, rowadd=None, rowadd_div=1, tile=0,
-           split_k=0, ln=None, sums=False):
+           split_k=0, ln=None, sums=False, rowmom=False):
     """out[M, n] = act(x @ w.T + bias) (+ resid).  ``x2``: second source of a channel concat ([x | x2] @ w.T).
-    ``ln=(rowsum fp32 [n], lnbias fp32 [n], eps)``: LayerNorm(x) folded into the GEMM (w must be gamma-scaled)."""
+    ``ln=(rowsum fp32 [n], lnbias fp32 [n], eps)``: LayerNorm(x) folded into the GEMM (w must be gamma-scaled).
+    ``rowmom``: ask for the row statistics of the OUTPUT (the LayerNorm that reads it next: ``row_stats_of``)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
     _rowmajor(x, "x")
     m = x.shape[0]
@@ -129,9 +143,9 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
         rowsum, lnbias, eps = ln[:3]
         _chk(rowsum, "ln rowsum", torch.float32), _chk(lnbias, "ln bias", torch.float32)
         d.ln_rowsum, d.ln_bias, d.ln_eps, d.split_k = rowsum.data_ptr(), lnbias.data_ptr(), eps, 1
-        stats = ln[3] if len(ln) > 3 and ln[3] is not None else row_stats(x, eps)  # (the library has no in-kernel statistics any more)
+        stats = ln[3] if len(ln) > 3 and ln[3] is not None else row_stats_of(x, eps)  # (the library has no in-kernel statistics any more)
         d.ln_stats = _chk(stats, "ln stats", torch.float32).data_ptr()
-    _gemm(d, x.device, out, sums)
+    _gemm(d, x.device, out, sums, rowmom)
     return out
 
 
@@ -334,6 +348,19 @@ def row_stats(x, eps=1e-5):
         raise RuntimeError("row_stats: x must be contiguous")
     out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
     check(lib.mvoc_row_stats_f16(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], eps, _stream()), "row_stats")
+    return out
+
+
+def row_stats_of(x, eps=1e-5):
+    """{mean, rstd} per row of x: from the row moments the producing GEMM left on the tensor (``_gemm``) when there are any -- a few
+    bytes per row instead of a pass over the tensor -- else ``row_stats``"""
+    rm = getattr(x, "row_moments", None)
+    if rm is None or not USE_ROW_MOMENTS or rm[0].shape[0] != x.shape[0]:
+        return row_stats(x, eps)
+    mom, tile_w = rm
+    out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+    check(lib.mvoc_row_stats_from_moments_f32(mom.data_ptr(), x.shape[0], mom.shape[1], x.shape[1], tile_w, eps, out.data_ptr(), _stream()),
+          "row_stats_from_moments")
     return out
 
 

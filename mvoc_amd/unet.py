@@ -154,13 +154,14 @@ class Linear:
 
     use_xs = os.environ.get("MVOC_XS", "1") != "0"  # MVOC_XS=0: A/B against the tiled GEMM (diagnostics)
 
-    def __call__(self, x, sums=False, **kw):
-        """``sums``: ask the GEMM for the GroupNorm statistics of its output (ops._gemm; the activation-stationary kernel has none)"""
+    def __call__(self, x, sums=False, rowmom=False, **kw):
+        """``sums`` / ``rowmom``: ask the GEMM for the GroupNorm / LayerNorm statistics of its output (ops._gemm; the
+        activation-stationary kernel has none -- its LayerNorm consumers normalise in registers)"""
         if self._xs_ok(x, kw):
             if self.wp is None:
                 self.wp = pack_xs_weights(self.w, self.b)
             return ops.xs_linear(x, self.wp, self.w.shape[0], n_store=self.n, **kw)
-        return ops.linear(x, self.w, self.b, n_store=self.n, sums=sums, **kw)
+        return ops.linear(x, self.w, self.b, n_store=self.n, sums=sums, rowmom=rowmom, **kw)
 
     def fold_layernorm(self, gamma, beta, eps=1e-5):
         """LayerNorm(x) @ W^T + b  ==  rstd * (x @ (W*gamma)^T - mean * rowsum(W*gamma)) + (beta @ W^T + b): the GEMM
@@ -187,7 +188,7 @@ class Linear:
             if self.wp_ln is None:
                 self.wp_ln = pack_xs_weights(self.w_ln, self.ln[1])
             return ops.xs_linear(x, self.wp_ln, self.w_ln.shape[0], normalize=True, eps=self.ln[2], n_store=self.n, **kw)
-        stats = ops.row_stats(x, self.ln[2])  # one read of the rows; every n-tile of the GEMM shares it
+        stats = ops.row_stats_of(x, self.ln[2])  # the producer's row moments, else one read of the rows; every n-tile shares it
         return ops.linear(x, self.w_ln, None, n_store=self.n, ln=self.ln + (stats,), **kw)
 
 
@@ -253,7 +254,7 @@ class Transformer2DModel(_TransformerBase):
         hw, nimg = H * W, B * F
         blk = self.transformer_blocks[0]
         h = ops.groupnorm(x, *self.norm, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h)
+        h = self.proj_in(h, rowmom=True)  # (norm1 reads it next)
         c = blk.dim
         # self-attention over the H*W tokens of each image
         qkv = blk.attn1.to_qkv.call_ln(h, blk.norm1)
@@ -276,7 +277,7 @@ class Transformer2DModel(_TransformerBase):
             ops.flash_attn(q[s1], k[s1], v[s1], nbatch=F, heads=self.heads, tq=hw, tk=hw, out=a[s1], v2=v[s2], out2=a[s2])
         else:
             a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
-        h = blk.attn1.to_out(a, resid=h)
+        h = blk.attn1.to_out(a, resid=h, rowmom=True)
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
         q2 = blk.attn2.to_q.call_ln(h, blk.norm2)
         kv = ctx.kv.get(self)
@@ -286,7 +287,7 @@ class Transformer2DModel(_TransformerBase):
                 ctx.kv[self] = kv
         a = ops.flash_attn(q2, kv[:, :c], kv[:, c:], nbatch=nimg, heads=self.heads, tq=hw, tk=ctx.length,
                            kv_bdiv=ctx.frames_per_ctx)
-        h = blk.attn2.to_out(a, resid=h)
+        h = blk.attn2.to_out(a, resid=h, rowmom=True)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
         return self.proj_out(h, resid=x, sums=True)  # (the next module opens with a GroupNorm of this tensor)
@@ -315,7 +316,7 @@ class TransformerTemporalModel(_TransformerBase):
         hw = H * W
         blk = self.transformer_blocks[0]
         h = eng.groupnorm5d(x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h)
+        h = self.proj_in(h, rowmom=True)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
             proc = attn.processor
@@ -323,7 +324,7 @@ class TransformerTemporalModel(_TransformerBase):
             if self.use_fused and attn.tfused is not None and not inject and F in ops.TFUSED_FRAMES and h.is_contiguous():
                 # Q/K/V never leave the chip: LayerNorm, projection and the frame attention of 32/F pixels per wave in one kernel
                 a = ops.temporal_qkv_attn(h, attn.tfused, attn.to_qkv.ln, nsample=B, frames=F, hw=hw, heads=self.heads)
-                h = attn.to_out(a, resid=h)
+                h = attn.to_out(a, resid=h, rowmom=True)
                 continue
             qkv = attn.to_qkv.call_ln(h, norm)
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
@@ -334,7 +335,7 @@ class TransformerTemporalModel(_TransformerBase):
                 ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
                                      f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background, ndst=ndst)
             a = ops.temporal_attn(q, k, v, nsample=B, frames=F, hw=hw, heads=self.heads)
-            h = attn.to_out(a, resid=h)
+            h = attn.to_out(a, resid=h, rowmom=True)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
         h = blk.ff2(f1, resid=h)
         return self.proj_out(h, resid=x, sums=True)  # (the next module opens with a GroupNorm of this tensor)

@@ -857,6 +857,55 @@ def test_gemm_chan_sums_and_groupnorm_from_them(ops, m, n, k, resid, tile):
     assert rel_l2(y_s, y_p) < 1e-4
 
 
+@pytest.mark.parametrize("m,n,k,resid,tile,act", [(2048, 640, 640, True, 82, 0), (2048, 640, 640, True, 81, 0), (1000, 1280, 1280, True, 82, 0),
+                                                  (4096, 512, 2048, True, 81, 0), (777, 1280, 640, False, 81, 0), (2048, 320, 960, False, 82, 0),
+                                                  (1536, 640, 2560, True, 82, 0), (1024, 768, 640, True, 81, 1)])
+def test_gemm_row_moments_and_layernorm_statistics_from_them(ops, m, n, k, resid, tile, act):
+    """LayerNorm statistics from the producer's epilogue (gemm8.hip: rowmom_pass): per row and n-tile the sums equal the sums of the
+    STORED fp16 values, the stored tensor is unchanged by the request, and {mean, rstd} merged from them equal mvoc_row_stats_f16 on
+    the same tensor to fp32 noise -- n-tiles of 256 and 320 channels with a partial last tile, rows past a 256-row tile, a
+    residual, an activation, a row with a mean far from its spread"""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = dev((torch.randn(m, k, generator=g) * 0.7).half())
+    w = dev((torch.randn(n, k, generator=g) / k ** 0.5).half())
+    b = dev(torch.randn(n, generator=g).half())
+    r = None
+    if resid:
+        rr = torch.randn(m, n, generator=g) * 2 + 1
+        rr[5] += 300.0   # a row whose mean dwarfs its spread (the case a one-pass variance loses)
+        r = dev(rr.half())
+    out = ops.linear(x, w, b, resid=r, tile=tile, split_k=1, act=ops.ACT_SILU if act else ops.ACT_NONE, rowmom=True)
+    rm = getattr(out, "row_moments", None)
+    assert rm is not None
+    mom, tw = rm
+    assert tw == (256 if tile == 81 or act else 320) and tuple(mom.shape) == (m, (n + 255) // 256, 2)
+    o = out.float()
+    for t in range((n + tw - 1) // tw):
+        sl = o[:, t * tw:min(n, (t + 1) * tw)]
+        assert torch.allclose(mom[:, t, 0], sl.sum(1), rtol=1e-5, atol=2e-3)
+        assert torch.allclose(mom[:, t, 1], (sl * sl).sum(1), rtol=1e-5, atol=2e-3)
+    plain = ops.linear(x, w, b, resid=r, tile=tile, split_k=1, act=ops.ACT_SILU if act else ops.ACT_NONE)
+    assert torch.equal(plain, out) and getattr(plain, "row_moments", None) is None
+    st_m = ops.row_stats_of(out, 1e-5)
+    st_p = ops.row_stats(plain, 1e-5)
+    assert torch.allclose(st_m[:, 0], st_p[:, 0], rtol=1e-5, atol=1e-4)
+    ref = o.double()
+    rstd = 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)
+    ordinary = torch.ones(m, dtype=torch.bool, device=out.device)
+    if resid:
+        ordinary[5] = False
+        # the row whose mean is ~150 x its spread: a tile's sum of squares minus its squared sum cancels 4-5 digits of fp32 --
+        # bounded here at 2e-3 on rstd (row_stats' two passes keep 1e-6); activations of the network sit at mean / spread < 10
+        assert abs(float(st_m[5, 1]) / float(rstd[5]) - 1) < 2e-3, (float(st_m[5, 1]), float(rstd[5]))
+    assert torch.allclose(st_m[ordinary, 1], st_p[ordinary, 1], rtol=2e-5, atol=0)
+    assert torch.allclose(st_m[ordinary, 1].double(), rstd[ordinary], rtol=2e-5)
+    # requests the kernel cannot honour leave the tensor without statistics: split-K slices, a column view
+    if k >= 2048 and m <= 8192:  # (a forced split is honoured only where the workspace policy provides the scratch)
+        sk = ops.linear(x, w, b, resid=r, tile=tile, split_k=2, rowmom=True)
+        assert getattr(sk, "row_moments", None) is None
+    assert getattr(ops.linear(x, w, b, resid=None, tile=tile, split_k=1, n_store=n - 64, rowmom=True), "row_moments", None) is None
+
+
 @pytest.mark.parametrize("c", [64, 320, 512, 1280])
 def test_layernorm(ops, c):
     g = torch.Generator().manual_seed(c)
