@@ -769,6 +769,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
+// The same reduction for launches whose consumer is a GroupNorm (chan_sums requested; no activation): one block per 256-row slab
+// and 32-channel strip -- thread = one row, its 32 channels in eight 16-byte groups -- so that the per-slab channel sums of the
+// STORED values (the contract of gemm8's stats_pass) come out of the pass that writes them: the 8 x 8 / 16 x 16 levels, whose
+// under-filled grids run split-K, then skip gn_partial like the levels above.  Sums in a fixed order (row by row): deterministic.
+__global__ __launch_bounds__(256) void splitk_reduce_sums_kernel(const GemmArgs p) {
+  // block = one 256-row slab x 32 channels; thread (row group rg = tid >> 3, channel quad cq = tid & 7) walks rows rg, rg + 32, ...:
+  // 8 threads read 128 contiguous bytes of a row, a wave 8 rows.  Its 8 rows' stored values are summed in registers, the 32 row
+  // groups meet in LDS and are added in a fixed order (deterministic sums).
+  __shared__ float ls[32][33], lq[32][33];
+  const int tid = threadIdx.x, rg = tid >> 3, cq = tid & 7;
+  const int n = blockIdx.y * 32 + 4 * cq;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[e] = (float)p.bias[n + e];
+  }
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int i = 0; i < 8; ++i) {
+    const int m = blockIdx.x * 256 + rg + 32 * i;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.split_k; ++s) a += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.N + n);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16(a[e] + bs[e]);
+    if (p.rowadd) {
+      const half4_t ra = *reinterpret_cast<const half4_t*>(p.rowadd + (size_t)(m / p.rowadd_div) * p.ld_rowadd + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)ra[e]);
+    }
+    if (p.resid) {
+      const half4_t rs = *reinterpret_cast<const half4_t*>(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = r16(v[e] + (float)rs[e]);
+    }
+    const half4_t o4 = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ldo + n) = o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f = (float)o4[e];
+      sx[e] += f;
+      sq[e] += f * f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ls[rg][4 * cq + e] = sx[e];
+    lq[rg][4 * cq + e] = sq[e];
+  }
+  __syncthreads();
+  if (tid < 64) {  // thread (channel, kind) adds the 32 row groups in order
+    const int c = tid & 31;
+    const float(*src)[33] = tid < 32 ? ls : lq;
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) acc += src[g][c];
+    p.stats[((size_t)blockIdx.x * p.n_store + blockIdx.y * 32 + c) * 2 + (tid >> 5)] = acc;
+  }
+}
+
 template <int WN, int WM, int TN, int TM, int NST = 2, int PF = 0, int BKK = 64, int PLAIN = 0>
 int launch_glds(const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
@@ -792,8 +852,12 @@ int launch_glds(const GemmArgs& a0, hipStream_t s) {
   }
   hipLaunchKernelGGL((gemm_glds_kernel<WN, WM, TN, TM, NST, PF, BKK, PLAIN>), dim3((unsigned)(nblk * a.split_k)), dim3(WN * WM * 64), 0, s, a);
   if (a.split_k > 1) {
-    const long nthr = (long)a.M * (a.N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+    if (a.stats) {  // (set by the caller only when splitk_reduce_sums_kernel's shape conditions hold)
+      hipLaunchKernelGGL(splitk_reduce_sums_kernel, dim3((unsigned)(a.M / 256), (unsigned)(a.N / 32)), dim3(256), 0, s, a);
+    } else {
+      const long nthr = (long)a.M * (a.N / 4);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+    }
   }
   return mvoc_check_launch("gemm_glds_kernel");
 }
@@ -822,6 +886,14 @@ extern "C" int mvoc_gemm_concurrency_hint(int n) {
   g_conc = n < 1 ? 1 : (n > 8 ? 8 : n);
   return old;
 }
+
+namespace {
+// splitk_reduce_sums_kernel reads bias / row-add / residual and writes the output in 8-byte groups of four channels
+bool sums_reduce_ok(const mvoc_gemm_desc* d) {
+  return d->ldo % 4 == 0 && ((uintptr_t)d->out & 7) == 0 && (!d->resid || (d->ldr % 4 == 0 && ((uintptr_t)d->resid & 7) == 0)) &&
+         (!d->rowadd || (d->ld_rowadd % 4 == 0 && ((uintptr_t)d->rowadd & 7) == 0));
+}
+}  // namespace
 
 extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   g_sums_written = 0;
@@ -989,6 +1061,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       a.split_k = sk;
       a.k_per_split = (int)(d->k / sk);
       a.ws = (float*)d->workspace;
+      if (!t8 && d->chan_sums && d->act == MVOC_ACT_NONE && a.M % 256 == 0 && a.N % 32 == 0 && a.n_store == a.N && sums_reduce_ok(d)) {
+        a.stats = (float*)d->chan_sums;  // the general tiles' split-K reduction emits the GroupNorm statistics too
+        g_sums_written = 1;
+      }
     }
   }
   if (g_trace) {
@@ -1023,6 +1099,12 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       const int rc = mvoc_launch_gemm8(a, tile == 81 ? 256 : 320, s, &bx_used);
       if (rc == 0 && a.rowmom) g_rowmom_bx = bx_used;
       if (rc == 0 && a.split_k > 1) {
+        if (d->chan_sums && d->act == MVOC_ACT_NONE && a.M % 256 == 0 && a.N % 32 == 0 && a.n_store == a.N && sums_reduce_ok(d)) {
+          a.stats = (float*)d->chan_sums;
+          g_sums_written = 1;
+          hipLaunchKernelGGL(splitk_reduce_sums_kernel, dim3((unsigned)(a.M / 256), (unsigned)(a.N / 32)), dim3(256), 0, s, a);
+          return mvoc_check_launch("splitk_reduce_sums_kernel");
+        }
         const long nthr = (long)a.M * (a.N / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
         return mvoc_check_launch("splitk_reduce_kernel");

@@ -857,6 +857,31 @@ def test_gemm_chan_sums_and_groupnorm_from_them(ops, m, n, k, resid, tile):
     assert rel_l2(y_s, y_p) < 1e-4
 
 
+@pytest.mark.parametrize("m,n,k,resid,tile,split", [(1024, 1280, 11520, True, 81, 4), (5120, 1280, 3840, False, 81, 2), (4096, 640, 5760, True, 82, 2),
+                                                    (1024, 1280, 2560, True, 11, 2), (1024, 1280, 23040, True, 0, 0)])
+def test_split_k_reduction_emits_channel_sums(ops, m, n, k, resid, tile, split):
+    """under-filled grids run split-K (the 8 x 8 / 16 x 16 levels): the reduction pass that writes the output also emits the
+    per-slab channel sums (gemm.hip: splitk_reduce_sums_kernel) -- same contract as the eight-phase tiles' stats_pass, same stored
+    tensor as the plain reduction, GroupNorm from them equal to the three-pass GroupNorm"""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = dev((torch.randn(m, k, generator=g) * 0.7).half())
+    w = dev((torch.randn(n, k, generator=g) / k ** 0.5).half())
+    b = dev(torch.randn(n, generator=g).half())
+    r = dev((torch.randn(m, n, generator=g) * 2 + 1).half()) if resid else None
+    out = ops.linear(x, w, b, resid=r, tile=tile, split_k=split, sums=True)
+    plain = ops.linear(x, w, b, resid=r, tile=tile, split_k=split)
+    assert torch.equal(plain, out)
+    cs = getattr(out, "chan_sums", None)
+    assert cs is not None and tuple(cs.shape) == (m // 256, n, 2)
+    o = out.float().reshape(m // 256, 256, n)
+    assert torch.allclose(cs[..., 0], o.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(cs[..., 1], (o * o).sum(1), rtol=1e-5, atol=1e-3)
+    gm, bt = dev((1 + 0.2 * torch.randn(n, generator=g)).half()), dev((0.2 * torch.randn(n, generator=g)).half())
+    y_s = ops.groupnorm(out, gm, bt, nsample=1, rows_per_sample=m, groups=32, eps=1e-5, silu=True)
+    y_p = ops.groupnorm(plain, gm, bt, nsample=1, rows_per_sample=m, groups=32, eps=1e-5, silu=True)
+    assert (y_s.float() - y_p.float()).abs().max() <= 4e-3 and rel_l2(y_s, y_p) < 1e-4
+
+
 @pytest.mark.parametrize("m,n,k,resid,tile,act", [(2048, 640, 640, True, 82, 0), (2048, 640, 640, True, 81, 0), (1000, 1280, 1280, True, 82, 0),
                                                   (4096, 512, 2048, True, 81, 0), (777, 1280, 640, False, 81, 0), (2048, 320, 960, False, 82, 0),
                                                   (1536, 640, 2560, True, 82, 0), (1024, 768, 640, True, 81, 1)])
