@@ -535,7 +535,8 @@ def test_flash_attn_pair_equals_two_calls(ops, fmode, t, heads, nb):
 
 
 @pytest.mark.parametrize("nb,heads,tq,tk,kv_bdiv,pair", [(2, 5, 4096, 4096, 1, 0), (2, 2, 920, 920, 1, 0), (2, 3, 1024, 1024, 1, 1), (4, 2, 300, 145, 2, 0),
-                                                         (1, 1, 130, 64, 1, 0), (1, 2, 2100, 2240, 1, 1), (2, 1, 129, 3600, 1, 0), (2, 2, 50, 129, 1, 1)])
+                                                         (1, 1, 130, 64, 1, 0), (1, 2, 2100, 2240, 1, 1), (2, 1, 129, 3600, 1, 0), (2, 2, 50, 129, 1, 1),
+                                                         (1, 5, 14399, 14399, 1, 0), (2, 2, 2049, 2049, 1, 1)])
 def test_flash_attn_kernels_agree_bitwise(ops, nb, heads, tq, tk, kv_bdiv, pair):
     """flash3_kernel (software-pipelined, LDS-DMA ring behind hand-counted waits) against flash_kernel on the same inputs: same
     fragment maps, rounding points and summation order, so every output bit must agree -- 1 to 64 key tiles, ragged last tiles
