@@ -334,6 +334,8 @@ template <int N>
 __device__ __forceinline__ void f3_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// waves per SIMD of the one-V form: 3 (168 registers, ring of three stages: 811-845 TFLOP/s at 4 096 keys) against 2 (ring of
+// four: 772-798) -- profiles/r4/flash3_ab.txt; -DF3_W1=2 rebuilds the other for A/B (tools/dbg/attn_ab.sh)
 #ifndef F3_W1
 #define F3_W1 3
 #endif
