@@ -11,7 +11,11 @@ update + latent hand-off, all inputs resident in HBM); the K timed steps cycle t
 [inversion, inversion, inversion, composition], so ``value`` = the job's average steps/s.  Synthetic latents /
 conditioning / seeded weights of the exact architecture (no checkpoint or dataset is reachable).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: one rank per GPU.  Launched by torch.distributed.run (RANK / WORLD_SIZE set) this process is one rank; launched plainly it
+starts the N ranks itself as child processes (`python -m torch.distributed.run ... bench.py <same flags>`, BEFORE anything here
+touches the GPU), relays rank 0's JSON line and exits with the children's status; N beyond the visible devices is refused.
 
 Multi-GPU: the per-object inversions and per-entry compositions are independent (reference loops at
 inverse.py:136, composite.py:87), so every rank runs its own shard of steps with NO data-path collective;
@@ -66,6 +70,10 @@ def parse():
                     help="diagnostic: the 3 source inversions of the job share one UNet call per step (batch 3, "
                          "I2VGenXLPipeline.invert_many) instead of three calls at batch 1; --steps must be a multiple of 4")
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allgather"], help="longclip: frame<->pixel exchange form")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="launcher self-test (runs WITHOUT a GPU, gloo): the ranks rendezvous, take the barrier / max-reduce "
+                         "bracket of the timed region around sleeps instead of UNet steps and rank 0 prints a line labelled as "
+                         "such -- covers `--gpus N` launched plainly (tests/test_config_launch_cpu.py); never a measurement")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="run under `rocprofv3 --pmc ...` (tools/pmc_bench.sh): eager launches, no priming, the K timed steps "
                          "bracketed by two marker kernels so that the counter rows of exactly these steps can be cut out")
@@ -160,8 +168,9 @@ class Job:
     def enable_concurrent_inversions(self):
         """the job's three source inversions (bg, obj1, obj2) as three batch-1 loops running AT THE SAME TIME on three HIP
         streams (I2VGenXLPipeline.invert_concurrent; `inverse.py --concurrent_entries 3`, the driver's default): every clip
-        replays its own captured iteration -- the launches, latents and files of the one-by-one form, bit for bit -- while the
-        other clips' kernels take the CUs a batch-1 launch leaves idle"""
+        replays its own captured iteration while the other clips' kernels take the CUs a batch-1 launch leaves idle.  Captured
+        with mvoc_gemm_desc.concurrency = 3 as the driver does: NOT the launches of the one-by-one form (the under-filled GEMMs
+        keep K in one piece, no split-K reduce), latents within one fp16 ulp per element and step of it, not bit-identical"""
         pipe = self.pipe
         saved, pipe._guidance_scale = pipe._guidance_scale, 1.0
         saved_sched, pipe.scheduler = pipe.scheduler, self.inv_sched
@@ -450,7 +459,10 @@ def cpu_baseline(frames, latent):
         "sample": f"BASELINE configs[0] in full: {steps1}-step DDIM inversion of one {f1}-frame {hw1 * 8}x{hw1 * 8} clip on the oracle "
                   f"(oracle/unet_ref.py + loops_ref.py, fp32 PyTorch CPU ops, {cores} threads) = {steps1 * fl_cfg1 / 1e12:.1f} TFLOP in "
                   f"{dt:.1f} s = {cfg1_sps:.3f} cfg1-steps/s; scaled by FLOPs ({fl_cfg1 / 1e12:.2f} -> {fl_step / 1e12:.2f} TFLOP) to the "
-                  f"job-mix step",
+                  f"job-mix step -- `value` is therefore an EXTRAPOLATION of the cfg 2 rate (the oracle's 16 x 64 x 64 steps were not "
+                  f"run: 1 warm-up + 2 measured steps at B = 1 and B = 5 cost ~7 min of host time); the >= 8x target of north_star "
+                  f"rests on it",
+        "extrapolated": True,
         "sample_seconds": round(dt, 2), "cfg1_steps_per_s": round(cfg1_sps, 4),
     }
 
@@ -525,13 +537,66 @@ def longclip(args, rank, world, device, dist):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without torchrun around it: start the N ranks as CHILD processes -- this parent has
+    made no HIP call (counting devices does not initialise the GPU) and never replaces itself -- relay what rank 0 prints and
+    return the launcher's exit status (non-zero as soon as one rank fails: torch.distributed.run tears the others down)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.selftest_launch:
+        visible = torch.cuda.device_count()
+        if n > visible and os.environ.get("MVOC_BENCH_OVERSUBSCRIBE") != "1":  # (the one-GPU test box runs two ranks on its GPU)
+            raise SystemExit(f"bench.py: --gpus {n} but only {visible} device(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:  # rank 0's JSON line (other ranks print nothing on stdout); stderr passes through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def selftest_launch(args, rank, world):
+    """the barrier / max-over-ranks bracket of the timed region around sleeps: checks the launch path, measures nothing"""
+    import torch.distributed as dist
+    if os.environ.get("MVOC_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)  # (the test of "exit non-zero if any rank fails")
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no kernels ran; not a measurement)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tt.item()) / args.steps * 1e3, 3),
+                          "scaling": "weak", "data": "none", "config": {"workload": "sleep"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_launch:
+        return selftest_launch(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     local_rank %= max(torch.cuda.device_count(), 1)  # (tests launch two ranks on a one-GPU box)
@@ -654,8 +719,11 @@ def main():
             "config": {
                 "workload": ("[--batch-inversions: the 3 inversion steps of each mix period run as ONE UNet call at batch 3] " if args.batch_inversions else "") +
                             ("[the 3 inversion steps of a mix period are one step of each of the job's three source clips (bg, obj1, obj2): "
-                             "independent batch-1 loops run on three HIP streams at the same time -- same launches, bit-identical latents, as "
-                             "one after the other; `sequential_inversions` below is that form] " if was_concurrent else "") +
+                             "independent batch-1 loops run on three HIP streams at the same time, captured with the GEMM concurrency hint 3 "
+                             "(mvoc_gemm_desc.concurrency: under-filled batch-1 GEMMs keep K in one piece instead of split-K + reduce, so "
+                             "the launches DIFFER from the one-after-the-other form and latents agree with it to one fp16 ulp per step, "
+                             "not bit for bit); `sequential_inversions` below is the rounds-1-3 form of the same K steps: un-hinted "
+                             "launches, one clip after the other] " if was_concurrent else "") +
                             f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "
                             f"(UNet batch 5 = bg+2 objects+uncond+cond, cfg 9.0; the demo's schedule: Q/K injection on every step, "
                             f"resnet / temporal-conv / conv_out feature injection on 5 of 50 -- every tenth composition step of the run; "
@@ -664,7 +732,9 @@ def main():
                             f"{args.frames} frames x {lat_w * 8}x{lat_h * 8}, 50-step DDIM schedules, fp16",
                 "frames": args.frames, "height": lat_h * 8, "width": lat_w * 8,
                 "unet_params": "1.42 B (I2VGen-XL architecture, seeded synthetic weights)",
-                "parallelism": "independent shards per GPU (no collectives)" if world > 1 else "single GPU",
+                "parallelism": (f"{world} independent shards, one per GPU, no data-path collective; every rank runs the whole job mix, i.e. "
+                                f"{3 if was_concurrent else 1} concurrent source clip(s) per rank" if world > 1 else
+                                f"single GPU, {3 if was_concurrent else 1} concurrent source clip(s)"),
                 "hip_graphs": not args.no_graphs,
                 "loop_invariant_conditioning": "context tokens, cross-attention K/V of them and the image-latent stem are computed once "
                                                "per loop (I2VGenXLUNet.prepare_conditioning), bit-identical to recomputing them per step",

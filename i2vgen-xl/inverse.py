@@ -66,11 +66,15 @@ def build_pipeline(device, synthetic):
     return pipe
 
 
-def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch, concurrent=False):
+def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch, concurrent=False, hint=1):
     """--batch_entries N: invert up to N pending clips of identical shape / step count in one batched loop
     (``I2VGenXLPipeline.invert_many``) before the per-entry pass below, which then finds their latents on disk.
     --concurrent_entries N (``concurrent``): the same grouping, but every clip keeps its own batch-1 loop and the N loops run at
-    the same time on N HIP streams (``I2VGenXLPipeline.invert_concurrent``): files bit-identical to the one-by-one pass."""
+    the same time on N HIP streams (``I2VGenXLPipeline.invert_concurrent``).  ``hint`` is passed on as its ``concurrency_hint``:
+    1 = exactly the launches of the one-by-one pass, files bit-identical to it; N > 1 (the driver's default: --concurrent_entries,
+    the SAME value for every group whatever its size, so a clip's files do not depend on how many others were pending) = the
+    under-filled GEMMs keep K in one piece and sum in another order: latents within one fp16 ulp per element and step of the
+    one-by-one pass, not bit-identical."""
     pending, done = [], set()  # done: output directories this pass produces (the per-entry pass must not invert them again,
     for entry in configs_list:  #       also not under force_recompute_latents)
         if not entry["active"]:
@@ -101,11 +105,13 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
         run = pipe.invert_concurrent if concurrent else pipe.invert_many
         run([g_[1].prompt for g_ in group], [g_[2] for g_ in group], lat, [g_[1].output_dir for g_ in group],
             height=inv0.image_size[1], width=inv0.image_size[0], target_fps=inv0.target_fps, num_frames=inv0.n_frames,
-            num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt)
+            num_inference_steps=inv0.n_steps, guidance_scale=inv0.cfg, negative_prompt=inv0.negative_prompt,
+            **({"concurrency_hint": int(hint)} if concurrent else {}))
     return done
 
 
-def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1, concurrent_entries=3):
+def main(template_config, configs_list, device, synthetic=False, frame_shard=None, batch_entries=1, concurrent_entries=3,
+         concurrency_hint=-1):
     pipe = build_pipeline(device, synthetic)
     if frame_shard is not None:
         pipe.enable_frame_shard(frame_shard)
@@ -116,7 +122,8 @@ def main(template_config, configs_list, device, synthetic=False, frame_shard=Non
     if batch_entries > 1:
         inverted = batched_inversions(pipe, inverse_scheduler, template_config, configs_list, batch_entries)
     elif concurrent_entries > 1 and frame_shard is None:
-        inverted = batched_inversions(pipe, inverse_scheduler, template_config, configs_list, concurrent_entries, concurrent=True)
+        inverted = batched_inversions(pipe, inverse_scheduler, template_config, configs_list, concurrent_entries, concurrent=True,
+                                      hint=concurrent_entries if concurrency_hint < 1 else concurrency_hint)
     for entry in configs_list:
         if not entry["active"]:
             logger.info(f"Skipping config_entry: {entry}")
@@ -172,7 +179,13 @@ if __name__ == "__main__":
                     help="invert up to N clips of identical shape in one batched UNet loop (one GPU, cfg 1.0 inversions)")
     ap.add_argument("--concurrent_entries", type=int, default=3,
                     help="invert up to N pending clips of identical shape at the same time, each in its own batch-1 loop on its own "
-                         "HIP stream (same launches per clip as the one-by-one pass, bit-identical files; 1 = one by one)")
+                         "HIP stream (1 = one by one)")
+    ap.add_argument("--concurrency_hint", type=int, default=-1,
+                    help="GEMM scheduling hint of the concurrent loops (mvoc_gemm_desc.concurrency), the same for every group. "
+                         "1: every clip runs exactly the launches of the one-by-one pass, ddim_latents_{t}.pt bit-identical to it. "
+                         "-1 (default): = --concurrent_entries: under-filled GEMMs keep K in one piece (6 %% faster); the files "
+                         "then differ from the one-by-one pass by fp16 rounding (<= 1 ulp per element and step), whatever the "
+                         "number of pending clips")
     args = ap.parse_args()
     template_config = OmegaConf.load(args.template_config)
     logging.basicConfig(level=logging.DEBUG if template_config.debug else logging.INFO,
@@ -193,4 +206,4 @@ if __name__ == "__main__":
         dist.destroy_process_group()
     else:
         main(template_config, my_entries(configs_list, args.shard), device, args.synthetic, batch_entries=args.batch_entries,
-             concurrent_entries=args.concurrent_entries)
+             concurrent_entries=args.concurrent_entries, concurrency_hint=args.concurrency_hint)

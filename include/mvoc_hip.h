@@ -76,15 +76,19 @@ typedef struct mvoc_gemm_desc {
                            BOTTOM / RIGHT only (F.pad(x, (0,1,0,1)) + conv2d(padding=0, stride=2): the downsamplers of the VAE
                            encoder, diffusers Downsample2D(padding=0)) */
   const void* ln_stats; /* {mean, rstd} per row, fp32 [m][2], from mvoc_row_stats_f16 (two-pass variance, one read of the rows, shared
-                           by every n-tile).  (Until round 4 a NULL here made each block accumulate E[x^2] - mean^2 in its K loop:
-                           the last one-pass variance of the library, removed.) */
-  void* chan_sums;      /* optional REQUEST, fp32 [ceil(m / 256)][n_store][2]: per 256-row slab and output channel, the sum and the
+                           by every n-tile) or mvoc_row_stats_from_moments_f32.  REQUIRED with ln_rowsum: the GEMM kernels take no
+                           row statistics themselves. */
+  void* chan_sums;      /* optional REQUEST, fp32 [m / 256][n_store][2] (honoured only when m is a multiple of 256): per 256-row slab
+                           and output channel, the sum and the
                            sum of squares of the values this call stores (fp16-rounded, residual included) -- the first pass of the
                            GroupNorm that reads `out` next (F.group_norm at pnp_utils.py:909-910, 953-965, 1048-1051, 185-188),
                            taken from the producer's epilogue instead of a separate read of the tensor.  Written only when the
                            launch runs on the eight-phase tiles without split-K and without activation: ask
                            mvoc_gemm_chan_sums_written() after the call; when it answers 0 the buffer is untouched and the
-                           consumer computes its own statistics (mvoc_groupnorm_f16 without chan_sums). */
+                           consumer computes its own statistics (mvoc_groupnorm_f16 without chan_sums).  These are ONE-PASS moments per
+                           slab (fp32-exact products summed in fp32); the consumers form M2 = sumsq - sum * mean per slab and channel
+                           group and Chan-merge the slabs, so cancellation is bounded by one slab's |mean| / sigma (as row_moments
+                           below: 2e-3 relative on rstd at |mean| / sigma = 150, far from this network's activations). */
   void* row_moments;    /* optional REQUEST, fp32 [m][row_moments_ld][2]: per output ROW and n-tile of the launch, the sum and the sum of
                            squares of the values this call stores over the tile's channels -- the statistics of the LayerNorm that
                            reads `out` next (F.layer_norm at pnp_utils.py:250-257, 296, 322), taken from the producer's epilogue
@@ -93,6 +97,11 @@ typedef struct mvoc_gemm_desc {
                            otherwise the tile width w (256 or 320): entry [r][t] covers channels [t w, min(n, (t + 1) w)), and
                            mvoc_row_stats_from_moments_f32 turns the entries of a row into its {mean, rstd}. */
   int32_t row_moments_ld; /* entries per row of row_moments: >= ceil(n / 256) */
+  int32_t concurrency;  /* scheduling hint, 0 / 1 = the launch has the chip to itself: the caller runs this many independent launches of
+                           this shape at the same time on other streams (the job's per-object inversions, inverse.py:136-190, as
+                           concurrent loops), so an under-filled grid need not be split over K to fill the chip.  Clamped to 8.  It
+                           changes the tile / split-K choice, hence the summation order of a launch (results differ from the unhinted
+                           launch by fp16 rounding of another order, never by more); per call, no process-wide state. */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);
@@ -104,11 +113,6 @@ int mvoc_gemm_row_moments_written(void);
  * {sum, sum of squares} become {count, mean, M2} per tile and are Chan-merged in tile order. */
 int mvoc_row_stats_from_moments_f32(const void* moments, int64_t rows, int32_t ld, int32_t n, int32_t tile_w, float eps,
                                     void* out_stats, void* stream);
-/* Scheduling hint for the tile / split-K choice of the calls that follow: the caller runs n independent launches of each shape at
- * the same time on n streams (the job's per-object inversions, inverse.py:136-190 as concurrent loops), so an under-filled grid
- * need not be split over K to fill the chip.  Process-wide, returns the previous value; 1 (the default) = alone.  Affects speed
- * only: every choice computes the same function. */
-int mvoc_gemm_concurrency_hint(int n);
 /* scratch for the deterministic split-K form of a launch: the most the auto policy uses is 8 slices of m*n fp32
  * partials; 0 when the policy would never split this shape (m > 8192 or k < 2048).  Passing no workspace is always valid:
  * the launch then runs unsplit. */

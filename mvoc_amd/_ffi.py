@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
                 ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("ln_rowsum", vp), ("ln_bias", vp),
                 ("ln_eps", f32), ("pad_mode", i32), ("ln_stats", vp), ("chan_sums", vp), ("row_moments", vp),
-                ("row_moments_ld", i32)]
+                ("row_moments_ld", i32), ("concurrency", i32)]
 
 
 class AttnDesc(C.Structure):
@@ -79,7 +79,6 @@ SIGNATURES = {
     "mvoc_gemm_chan_sums_written": (i32, []),
     "mvoc_gemm_row_moments_written": (i32, []),
     "mvoc_row_stats_from_moments_f32": (i32, [vp, i64, i32, i32, i32, f32, vp, vp]),
-    "mvoc_gemm_concurrency_hint": (i32, [i32]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
     "mvoc_flash_pipelined": (None, [i32]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),

@@ -870,22 +870,12 @@ extern "C" size_t mvoc_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 }
 
 namespace {
-// How many independent launches of the same shape the caller runs at the same time on other streams (the job's three source
-// inversions: pipeline.invert_concurrent).  The dispatch below prices a grid's fill and decides on split-K as if the grid were
-// this many times larger: an under-filled batch-1 launch then keeps its K in one piece (no fp32 slabs, no reduce pass) and lets
-// the other clips' blocks take the idle CUs.  1 = the launch has the chip to itself.
-int g_conc = 1;
 thread_local int g_sums_written = 0;
 thread_local int g_rowmom_bx = 0;
 const bool g_trace = getenv("MVOC_GEMM_TRACE") != nullptr;  // diagnostics: one line per launch with the dispatch decision
 }
 extern "C" int mvoc_gemm_chan_sums_written(void) { return g_sums_written; }
 extern "C" int mvoc_gemm_row_moments_written(void) { return g_rowmom_bx; }
-extern "C" int mvoc_gemm_concurrency_hint(int n) {
-  const int old = g_conc;
-  g_conc = n < 1 ? 1 : (n > 8 ? 8 : n);
-  return old;
-}
 
 namespace {
 // splitk_reduce_sums_kernel reads bias / row-add / residual and writes the output in 8-byte groups of four channels
@@ -960,6 +950,11 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   }
   int tile = d->tile;
   int model_sk = 0, g8_sk = 0;
+  // mvoc_gemm_desc.concurrency: how many independent launches of this shape the caller runs at the same time on other streams (the
+  // job's three source inversions: pipeline.invert_concurrent).  The dispatch below prices a grid's fill and decides on split-K as
+  // if the grid were this many times larger: an under-filled batch-1 launch then keeps its K in one piece (no fp32 slabs, no
+  // reduce pass) and lets the other clips' blocks take the idle CUs.
+  const int conc = d->concurrency < 1 ? 1 : (d->concurrency > 8 ? 8 : d->concurrency);
   // ---- eight-phase tiles (gemm8.hip): 81 = 256 channels x 256 pixels per block, 82 = 320 x 256 ------------------------------
   const int64_t rows_a = d->a_mode == MVOC_A_CONV3X3 ? (int64_t)d->nimg * d->hsrc * d->wsrc : d->m;
   const int64_t lim = (int64_t)1 << 31;  // 32-bit MUBUF offsets, rows beyond the range read zeros
@@ -979,7 +974,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     // (Until the epilogue forms were split -- gemm8.hip, EPI -- the short-K projections, n and k <= 640, were faster on the
     // general tiles; with the 3 k-tick plain epilogue they are 30-45 % faster here.)
     auto eff = [&](int bx, double rate) {
-      const int64_t nt = (d->n + bx - 1) / bx, blocks = ((d->m + 255) / 256) * nt * g_conc;
+      const int64_t nt = (d->n + bx - 1) / bx, blocks = ((d->m + 255) / 256) * nt * conc;
       return (double)d->n / (double)(nt * bx) * (double)blocks / (double)(((blocks + 255) / 256) * 256) * rate;
     };
     const double e81 = eff(256, 1.0);
@@ -989,7 +984,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
       // deep K on a grid of 64..190 tiles (the 16x16 / 8x8 levels): K slices bring the grid to one block per CU; measured
       // 1.2-1.4x over the split-K form of the 128-wide tiles (M = 4096 / 5120, K = 3840 .. 23040)
-      const int64_t blocks = ((d->m + 255) / 256) * ((d->n + 255) / 256) * g_conc;
+      const int64_t blocks = ((d->m + 255) / 256) * ((d->n + 255) / 256) * conc;
       if (blocks >= 64 && blocks < 190) {
         for (int sk = (int)(256 / blocks) > 4 ? 4 : (int)(256 / blocks); sk >= 2; --sk)
           if (d->k % (64 * sk) == 0 && (size_t)sk * d->m * d->n * 4 <= d->workspace_bytes) {
@@ -1024,7 +1019,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       for (const auto& c : cand) {
         if (d->n % c.bn) continue;
         if (c.bm == 256 && d->m < 65536) continue;  // measured: below 64 K rows the 256-row tile's tail costs more than the model says
-        const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn) * g_conc;
+        const long blocks = ((d->m + c.bm - 1) / c.bm) * ((d->n + c.bn - 1) / c.bn) * conc;
         int sk = 1;
         if (can_split && blocks < 384 && c.bm == 128)
           while (sk < 8 && blocks * sk < 512 && d->k % (64 * sk * 2) == 0 && d->k / (sk * 2) >= 512) sk *= 2;
@@ -1050,7 +1045,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     const bool t8 = tile == 81 || tile == 82;
     const int bm = t8 || tile == 64 ? 256 : 128;
     const int bn = tile == 82 ? 320 : tile == 81 ? 256 : (tile % 10 == 2 || tile == 64) ? 160 : (tile % 10 == 3 ? 64 : 128);
-    const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn) * g_conc;
+    const long blocks = ((d->m + bm - 1) / bm) * ((d->n + bn - 1) / bn) * conc;
     int sk = d->split_k > 1 ? d->split_k : 1;
     if (model_sk > 0) {
       sk = model_sk;
@@ -1086,7 +1081,8 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
           a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
         }
       }
-      if (d->chan_sums && a.split_k == 1 && d->act == MVOC_ACT_NONE) {  // statistics of the stored tile from the epilogue
+      if (d->chan_sums && a.split_k == 1 && d->act == MVOC_ACT_NONE && a.M % 256 == 0) {  // statistics of the stored tile from the epilogue
+        // (whole 256-row tiles only: stats_pass sums the tile as it stands in LDS, phantom rows >= M included)
         a.stats = (float*)d->chan_sums;
         g_sums_written = 1;
       }

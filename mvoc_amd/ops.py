@@ -5,6 +5,7 @@ All activations are fp16, channels-last 2-D ``[rows, C]`` tensors (rows = B*F*H*
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -42,6 +43,11 @@ def _rowmajor(t, name):
     return t.stride(0)
 
 
+class _Conc(threading.local):
+    n = 1
+
+
+_CONCURRENCY = _Conc()
 USE_ROW_MOMENTS = os.environ.get("MVOC_ROW_MOMENTS", "1") != "0"  # LayerNorm statistics from the producing GEMM's epilogue
 
 
@@ -53,7 +59,12 @@ def _gemm(d: GemmDesc, dev=None, out=None, sums=False, rowmom=False):
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     cs = None
-    if sums and out is not None and d.m % 256 == 0 and d.act == ACT_NONE and out.is_contiguous():
+    if out is not None:  # statistics ride on the tensor OBJECT: whatever an earlier producer hung on a caller-supplied `out` is stale now
+        for attr in ("chan_sums", "row_moments"):
+            if hasattr(out, attr):
+                delattr(out, attr)
+    d.concurrency = _CONCURRENCY.n
+    if sums and out is not None and d.m % 256 == 0 and d.act == ACT_NONE and out.is_contiguous() and out.shape[1] == d.n_store:
         # REQUEST for the producer-epilogue GroupNorm statistics (include/mvoc_hip.h: chan_sums); honoured by the eight-phase tiles
         cs = torch.empty((d.m // 256, out.shape[1], 2), dtype=torch.float32, device=out.device)
         d.chan_sums = cs.data_ptr()
@@ -73,18 +84,19 @@ def _gemm(d: GemmDesc, dev=None, out=None, sums=False, rowmom=False):
 
 
 class gemm_concurrency:
-    """``with gemm_concurrency(n):`` -- the GEMM launches issued (or CAPTURED) inside run beside n - 1 independent launches of the
-    same shape on other streams (include/mvoc_hip.h: mvoc_gemm_concurrency_hint)"""
+    """``with gemm_concurrency(n):`` -- the GEMM launches issued (or CAPTURED) inside by THIS thread run beside n - 1 independent
+    launches of the same shape on other streams; passed to every call as ``mvoc_gemm_desc.concurrency`` (include/mvoc_hip.h).
+    Host-side and thread-local: the library itself keeps no such state."""
 
     def __init__(self, n):
-        self.n = int(n)
+        self.n = max(1, int(n))
 
     def __enter__(self):
-        self.old = lib.mvoc_gemm_concurrency_hint(self.n)
+        self.old, _CONCURRENCY.n = _CONCURRENCY.n, self.n
         return self
 
     def __exit__(self, *exc):
-        lib.mvoc_gemm_concurrency_hint(self.old)
+        _CONCURRENCY.n = self.old
 
 
 def chan_sums_of(x, rows_per_sample):

@@ -365,13 +365,18 @@ class I2VGenXLPipeline:
         per-object inversions of a composition job are independent (``inverse.py:136-190`` runs them one after another; on a
         node they shard one per GPU): on one GPU their kernels interleave, and wherever a batch-1 launch cannot fill the chip --
         the 16x16 / 8x8 levels run 80-240 workgroups on 256 CUs, the small norm / statistics kernels are latency-bound -- another
-        clip's kernels take the idle CUs.  Every clip still runs exactly the launches of ``invert`` (one captured iteration per
-        clip); replaying the n iterations concurrently or one after the other gives bit-identical latents and files (measured:
-        32.5 -> 26.7 ms per clip-step at three clips, profiles/r4).  ``concurrency_hint`` (default): the iterations are captured
-        with ``mvoc_gemm_concurrency_hint(n)``, so GEMMs whose batch-1 grid cannot fill the chip keep their K in one piece (no
-        split-K slabs / reduce pass: the other clips fill the idle CUs) -- 25.5 ms per clip-step; against ``invert`` those GEMMs
-        then sum in another order (rel-L2 5e-5 after a step on the 1.42 B network); ``False`` keeps ``invert``'s launches exactly
-        (bit-identical to it).  Same return value per clip as ``invert``."""
+        clip's kernels take the idle CUs (32.5 -> 26.7 ms per clip-step at three clips, profiles/r4).  Same return value per clip
+        as ``invert``.
+
+        ``concurrency_hint``: the value every GEMM of the captured iterations carries in ``mvoc_gemm_desc.concurrency``.
+        ``False`` / ``1``: every clip runs exactly the launches of ``invert`` -- latents and ``ddim_latents_{t}.pt`` files are
+        BIT-IDENTICAL to the one-by-one pass (asserted at production width in tests/test_fullwidth_gpu.py).  ``True`` (default):
+        the hint is the number of clips of this call; an ``int`` fixes it whatever the group size (the driver passes its
+        ``--concurrent_entries`` so that a clip's files do not depend on how many other clips happened to be pending).  With a hint
+        > 1 the GEMMs whose batch-1 grid cannot fill the chip keep their K in one piece (no split-K slabs / reduce pass: the other
+        clips fill the idle CUs; 25.5 ms per clip-step) and therefore sum in another order than under ``invert``: the latents then
+        differ from the one-by-one pass by fp16 rounding (rel-L2 5e-5, <= 1 fp16 ulp per element after a step on the 1.42 B
+        network; same test), inside the per-step tolerance but NOT bit-identical."""
         n = len(prompts)
         if not (len(images) == len(latents) == len(output_dirs) == n and n > 0):
             raise ValueError("invert_concurrent: prompts, images, latents and output_dirs must have the same length")
@@ -388,17 +393,22 @@ class I2VGenXLPipeline:
             cond = self._stock_conditioning(prompts[j], negative_prompt, images[j], num_frames, height, width, target_fps, None, None,
                                             None, None)
             lat = self.prepare_latents(1, 4, num_frames, height, width, H16, self.device, None, latents[j])
-            hint = n if concurrency_hint else 1
+            hint = (n if concurrency_hint is True else max(1, int(concurrency_hint)))
             key = ("stock-concurrent", j, hint, tuple(lat.shape), guidance_scale > 1, bool(self.use_graphs),
                    tuple((k, tuple(v.shape)) for k, v in sorted(cond.items())))
-            st = self._concurrent_states.get(key)
+            st = self._concurrent_states.pop(key, None)
             if st is None:
                 with ops.gemm_concurrency(hint):  # (baked into the captured iteration: tile / split-K choices)
-                    st = self._concurrent_states[key] = self._make_stock_step(key, lat, cond, guidance_scale)
+                    st = self._make_stock_step(key, lat, cond, guidance_scale)
             else:
                 st["load_cond"](cond)
+            self._concurrent_states[key] = st  # (re-)inserted at the end: least recently used first
             st["latents"].copy_(lat)
             states.append(st)
+        # each entry pins a UNet graph and its private activation pool: keep this call's states plus at most as many older ones
+        # as `_graphs` may hold (a job that alternates two shapes keeps both, a long multi-shape job does not grow without bound)
+        while len(self._concurrent_states) > n + self.max_cached_graphs:
+            self._concurrent_states.pop(next(iter(self._concurrent_states)))
         while len(self._streams) < n:
             self._streams.append(torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream()

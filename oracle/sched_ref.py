@@ -8,7 +8,7 @@ scheduler config is the one shipped with ``ali-vilab/i2vgen-xl`` (recalled): 100
 ``squaredcos_cap_v2`` betas, ``v_prediction``, ``rescale_betas_zero_snr``, ``timestep_spacing='leading'``,
 ``steps_offset=1``, ``set_alpha_to_one``, no clipping, eta=0.  **Parity unpinned**: the reference holds no
 test or golden vector for it; the only anchor is the comment ``0 for 981, 3 for 921, 9 for 801, 20 for 581``
-at ``i2vgen-xl/configs/group_composite/template.yaml:43``, which ``tests/test_schedulers.py`` checks.
+at ``i2vgen-xl/configs/group_composite/template.yaml:43``, which ``tests/test_host_cpu.py`` checks (the timestep list), beside the closed-form properties tested there.
 
 dtype behaviour restated: sample / model_output keep their dtype (fp16 on the GPU path); the alpha
 factors are fp32 scalars, so every product and sum is rounded to the tensor dtype once per op.

@@ -72,6 +72,36 @@ def test_two_process_gloo_launch(tmp_path):
     assert out[0]["tmax"] == out[1]["tmax"] == pytest.approx(0.2)
 
 
+def test_bench_gpus2_launched_plainly_starts_two_ranks():
+    """the driver's command form `python bench.py --gpus N ...` with no torchrun around it: bench.py starts the N ranks itself
+    (child processes, before any GPU call), relays rank 0's ONE JSON line, and says n_gpus = N (launcher self-test mode: gloo,
+    sleeps instead of UNet steps -- this container has no GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--selftest-launch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["ms_per_step"] >= 2.0  # the MAX over ranks (rank 1 sleeps 2 ms per step, rank 0 one)
+
+
+def test_bench_self_launch_fails_when_a_rank_fails_and_refuses_too_many_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, MVOC_BENCH_SELFTEST_FAIL_RANK="1"))
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # the real workload: more ranks than visible devices is refused before anything is launched (no GPU here: 0 visible)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64", "--steps", "4"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)
+    # and a rank count that contradicts the launcher's WORLD_SIZE is an error, never a silent one-GPU run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "4", "--selftest-launch"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
 def test_flop_model_matches_survey():
     """2.48 / 20.96 / 104.82 TFLOP per UNet forward"""
     from mvoc_amd.flops import unet_flops

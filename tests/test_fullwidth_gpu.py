@@ -221,6 +221,74 @@ def test_one_inversion_and_one_composition_step_full_width(pair, trio):
         assert rel <= REL_L2_STEP, rel  # (measured 1.5e-4: at t = 981 the update is dominated by the latent itself)
 
 
+def _ulp_distance(a, b):
+    """largest distance between two fp16 tensors in units in the last place (monotone integer image of the fp16 line)"""
+    def key(t):
+        i = t.contiguous().view(torch.int16).to(torch.int32)
+        return torch.where(i < 0, -(i & 0x7FFF), i)
+    return int((key(a) - key(b)).abs().max())
+
+
+def test_hinted_inversion_step_full_width(pair, tmp_path):
+    """the dispatch the headline's concurrent inversions are captured under (``mvoc_gemm_desc.concurrency = 3``: under-filled GEMMs
+    keep K in one piece instead of split-K + reduce) at PRODUCTION width, where it does change launches: one captured inversion
+    step with the hint against the oracle (the loop tolerance) and against the un-hinted step (how far apart the two summation
+    orders land); and ``invert_concurrent(concurrency_hint=False)`` against ``invert``: bit-identical latents and files."""
+    import os
+    from oracle import loops_ref, sched_ref
+    from mvoc_amd import ops
+    from mvoc_amd.pipeline import I2VGenXLPipeline
+    from mvoc_amd.schedulers import DDIMInverseScheduler
+    o, eng = pair
+    g = torch.Generator().manual_seed(11)
+    f = 16
+    x = _inputs(g, 1, f)
+    x0 = x["sample"].half()
+    pipe = I2VGenXLPipeline(eng, DDIMInverseScheduler(), use_graphs=True)
+    pipe.latent_cache.write_files = False
+    cond = dict(encoder_hidden_states=x["eh"].half().cuda(), image_embeddings=x["ie"][:, :1].half().cuda(),
+                image_latents=x["il"].half().cuda(), fps=torch.full((1,), 8.0, device="cuda"))
+    sched = pipe.scheduler
+    sched.set_timesteps(50, device="cuda")
+    table, index = sched.coef_table(eng.device, 1.0)
+    t = int(sched.timesteps[0])
+    got = {}
+    for hint in (1, 3):
+        with ops.gemm_concurrency(hint):
+            st = pipe._make_stock_step(f"hint{hint}", x0.cuda(), cond, 1.0)
+        st["t"].fill_(float(t))
+        st["coef"].copy_(table[index[t]])
+        st["run"]()
+        torch.cuda.synchronize()
+        got[hint] = st["latents"].clone()
+    rsi = sched_ref.DDIMInverseSchedulerRef()
+    rsi.set_timesteps(50)
+    noise = o(x0.float(), t, x["fps"], x["il"], x["ie"][:, :1], x["eh"])[0].half()
+    ref = loops_ref.scheduler_step_5d(rsi, noise, t, x0)
+    rel1, _ = _metrics(got[1], ref)
+    rel3, _ = _metrics(got[3], ref)
+    rel13, _ = _metrics(got[3], got[1])
+    ulp = _ulp_distance(got[3], got[1])
+    ndiff = int((got[3] != got[1]).sum())
+    print(f"full-width inversion step, GEMM concurrency hint 1 / 3: rel-L2 vs oracle {rel1:.2e} / {rel3:.2e}; hinted vs un-hinted: "
+          f"rel-L2 {rel13:.2e}, {ndiff} of {got[1].numel()} elements differ, largest distance {ulp} fp16 ulp")
+    assert rel1 <= REL_L2_STEP and rel3 <= REL_L2_STEP, (rel1, rel3)
+    assert ndiff > 0, "the hint changed no launch at this size: the test would be vacuous"
+    assert rel13 <= 2e-4 and ulp <= 2, (rel13, ulp)
+    # ---- without the hint the concurrent form IS the one-by-one pass: latents and files bit for bit ------------------
+    pipe.latent_cache.write_files = True
+    kw = dict(height=H * 8, width=W * 8, num_frames=f, num_inference_steps=2, guidance_scale=1.0, target_fps=8)
+    lats = [x0.cuda(), x0.flip(3).cuda()]
+    one = [pipe.invert(latents=lats[j], prompt=f"p{j}", image=f"img{j}", return_dict=False, output_dir=str(tmp_path / f"a{j}"), **kw)
+           for j in range(2)]
+    conc = pipe.invert_concurrent([f"p{j}" for j in range(2)], [f"img{j}" for j in range(2)], lats,
+                                  [str(tmp_path / f"b{j}") for j in range(2)], concurrency_hint=False, **kw)
+    for j in range(2):
+        assert torch.equal(one[j], conc[j])
+        for name in sorted(os.listdir(tmp_path / f"a{j}")):
+            assert torch.equal(torch.load(tmp_path / f"a{j}" / name), torch.load(tmp_path / f"b{j}" / name)), name
+
+
 def test_cfg1_8frame_256sq_10step_inversion(pair, tmp_path):
     """BASELINE.json configs[0]: a single 8-frame 256x256 clip, 10-step DDIM inversion -- the HIP loop (graph replay)
     against the oracle loop on the same inputs; files and return layout as the reference writes them"""
