@@ -170,7 +170,7 @@ class Job:
         streams (I2VGenXLPipeline.invert_concurrent; `inverse.py --concurrent_entries 3`, the driver's default): every clip
         replays its own captured iteration while the other clips' kernels take the CUs a batch-1 launch leaves idle.  Captured
         with mvoc_gemm_desc.concurrency = 3 as the driver does: NOT the launches of the one-by-one form (the under-filled GEMMs
-        keep K in one piece, no split-K reduce), latents within one fp16 ulp per element and step of it, not bit-identical"""
+        keep K in one piece, no split-K reduce), latents within rel-L2 5e-5 per step of it (fp16 rounding noise), not bit-identical"""
         pipe = self.pipe
         saved, pipe._guidance_scale = pipe._guidance_scale, 1.0
         saved_sched, pipe.scheduler = pipe.scheduler, self.inv_sched
@@ -721,7 +721,7 @@ def main():
                             ("[the 3 inversion steps of a mix period are one step of each of the job's three source clips (bg, obj1, obj2): "
                              "independent batch-1 loops run on three HIP streams at the same time, captured with the GEMM concurrency hint 3 "
                              "(mvoc_gemm_desc.concurrency: under-filled batch-1 GEMMs keep K in one piece instead of split-K + reduce, so "
-                             "the launches DIFFER from the one-after-the-other form and latents agree with it to one fp16 ulp per step, "
+                             "the launches DIFFER from the one-after-the-other form and latents agree with it to rel-L2 5e-5 per step, "
                              "not bit for bit); `sequential_inversions` below is the rounds-1-3 form of the same K steps: un-hinted "
                              "launches, one clip after the other] " if was_concurrent else "") +
                             f"boat_surf demo job mix: 3 DDIM-inversion steps (UNet batch 1, cfg 1.0) : 1 PnP composition step "

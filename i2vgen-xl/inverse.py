@@ -73,8 +73,8 @@ def batched_inversions(pipe, inverse_scheduler, template_config, configs_list, b
     the same time on N HIP streams (``I2VGenXLPipeline.invert_concurrent``).  ``hint`` is passed on as its ``concurrency_hint``:
     1 = exactly the launches of the one-by-one pass, files bit-identical to it; N > 1 (the driver's default: --concurrent_entries,
     the SAME value for every group whatever its size, so a clip's files do not depend on how many others were pending) = the
-    under-filled GEMMs keep K in one piece and sum in another order: latents within one fp16 ulp per element and step of the
-    one-by-one pass, not bit-identical."""
+    under-filled GEMMs keep K in one piece and sum in another order: latents within rel-L2 5e-5 per step of the one-by-one
+    pass (fp16 rounding noise), not bit-identical."""
     pending, done = [], set()  # done: output directories this pass produces (the per-entry pass must not invert them again,
     for entry in configs_list:  #       also not under force_recompute_latents)
         if not entry["active"]:
@@ -184,7 +184,7 @@ if __name__ == "__main__":
                     help="GEMM scheduling hint of the concurrent loops (mvoc_gemm_desc.concurrency), the same for every group. "
                          "1: every clip runs exactly the launches of the one-by-one pass, ddim_latents_{t}.pt bit-identical to it. "
                          "-1 (default): = --concurrent_entries: under-filled GEMMs keep K in one piece (6 %% faster); the files "
-                         "then differ from the one-by-one pass by fp16 rounding (<= 1 ulp per element and step), whatever the "
+                         "then differ from the one-by-one pass by fp16 rounding noise (rel-L2 5e-5 per step), whatever the "
                          "number of pending clips")
     args = ap.parse_args()
     template_config = OmegaConf.load(args.template_config)

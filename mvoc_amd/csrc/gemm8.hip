@@ -139,6 +139,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     mtile = g8_udiv(logical, p.mg_nt, p.sh_nt);
     ntile = logical - mtile * (unsigned)p.n_tiles;
   }
+  if (p.tmap_t > 0) {
+    // Temporal conv (rows [video][frame][pixel]): a tile's three taps are the same 256 pixels of frames f - 1, f, f + 1.  In row
+    // order those are hw / 256 tiles apart -- at 64 x 64 sixteen tiles, half a round of an XCD's 32 resident blocks, 2.6 MB of
+    // other rows in between -- and every activation line came from beyond L2 three times (profiles/r4/pmc_gemm_traffic.json: the
+    // 320-wide form fetched 490 MB per launch for 84 MB of rows).  Frame-fastest: the 32 tiles an XCD runs at a time are 2 (8, 32)
+    // patches x all 16 frames, so a line is fetched once and its other two readers hit L2.
+    const unsigned per = (unsigned)p.tmap_t * (unsigned)p.frames;
+    const unsigned vid = g8_udiv(mtile, p.mg_tm, p.sh_tm);
+    const unsigned r_ = mtile - vid * per;
+    const unsigned patch = g8_udiv(r_, p.mg_fr, p.sh_fr);
+    mtile = vid * per + (r_ - patch * (unsigned)p.frames) * (unsigned)p.tmap_t + patch;
+  }
   const int n0 = (int)ntile * BX;
   const int m0 = (int)mtile * 256;
   const int kbeg = slice * p.k_per_split;
@@ -771,6 +783,13 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
     a.band = force ? force : (a.n_tiles >= 8 ? 4 : a.n_tiles >= 4 ? 2 : 1);
     if (a.band > a.m_tiles) a.band = 1;
     g8_magic((unsigned)(a.band * a.n_tiles), a.mg_band, a.sh_band);
+  }
+  {
+    static const bool off = getenv("MVOC_G8_TMAP") && atoi(getenv("MVOC_G8_TMAP")) == 0;  // diagnostics: row order
+    a.tmap_t = 0;
+    if (!off && a.a_mode == MVOC_A_TEMPORAL3 && a.frames > 1 && a.hw % 256 == 0 && a.M % (a.frames * a.hw) == 0 && a.hw / 256 > 1)
+      a.tmap_t = a.hw / 256;
+    g8_magic((unsigned)(a.tmap_t > 0 ? a.tmap_t * a.frames : 1), a.mg_tm, a.sh_tm);
   }
   g8_magic((unsigned)a.split_k, a.mg_sk, a.sh_sk);
   g8_magic((unsigned)(a.hout * a.wout), a.mg_hwout, a.sh_hwout);

@@ -31,6 +31,10 @@ struct GemmArgs {
   unsigned mg_nt, mg_sk, mg_hwout, mg_wout, mg_hw, mg_fr, mg_ra, mg_band;
   int sh_nt, sh_sk, sh_hwout, sh_wout, sh_hw, sh_fr, sh_ra, sh_band;
   int band;  // gemm8 tile order: m-tiles per band (gemm8.hip)
+  // gemm8, temporal conv: m-tiles walk the FRAMES of one 256-pixel patch before the next patch (tmap_t = patches per frame, 0 =
+  // off): the three taps of a tile are then the tiles its XCD runs beside it, not 16 tiles away (gemm8.hip)
+  int tmap_t, sh_tm;
+  unsigned mg_tm;
   float* stats;  // gemm8, optional: per 256-row tile and output channel {sum, sum of squares} of the stored values, fp32 [m_tiles][n_store][2]
   float* rowmom;  // gemm8, optional: per output row and n-tile {sum, sum of squares} of the stored values, fp32 [M][rowmom_ld][2]
   int rowmom_ld;

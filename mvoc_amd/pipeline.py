@@ -375,7 +375,7 @@ class I2VGenXLPipeline:
         ``--concurrent_entries`` so that a clip's files do not depend on how many other clips happened to be pending).  With a hint
         > 1 the GEMMs whose batch-1 grid cannot fill the chip keep their K in one piece (no split-K slabs / reduce pass: the other
         clips fill the idle CUs; 25.5 ms per clip-step) and therefore sum in another order than under ``invert``: the latents then
-        differ from the one-by-one pass by fp16 rounding (rel-L2 5e-5, <= 1 fp16 ulp per element after a step on the 1.42 B
+        differ from the one-by-one pass by fp16 rounding of another summation order (rel-L2 5e-5 after a step on the 1.42 B
         network; same test), inside the per-step tolerance but NOT bit-identical."""
         n = len(prompts)
         if not (len(images) == len(latents) == len(output_dirs) == n and n > 0):

@@ -268,13 +268,16 @@ def test_hinted_inversion_step_full_width(pair, tmp_path):
     rel1, _ = _metrics(got[1], ref)
     rel3, _ = _metrics(got[3], ref)
     rel13, _ = _metrics(got[3], got[1])
-    ulp = _ulp_distance(got[3], got[1])
+    big = got[1].abs() >= 0.25  # (an ulp distance only means something away from zero: latents are ~N(0, 1))
+    ulp = _ulp_distance(got[3][big], got[1][big])
+    dmax = float((got[3].float() - got[1].float()).abs().max())
     ndiff = int((got[3] != got[1]).sum())
     print(f"full-width inversion step, GEMM concurrency hint 1 / 3: rel-L2 vs oracle {rel1:.2e} / {rel3:.2e}; hinted vs un-hinted: "
-          f"rel-L2 {rel13:.2e}, {ndiff} of {got[1].numel()} elements differ, largest distance {ulp} fp16 ulp")
+          f"rel-L2 {rel13:.2e}, {ndiff} of {got[1].numel()} elements differ, largest |difference| {dmax:.2e} "
+          f"(max |latent| {float(got[1].abs().max()):.2f}), at most {ulp} fp16 ulp on elements >= 0.25")
     assert rel1 <= REL_L2_STEP and rel3 <= REL_L2_STEP, (rel1, rel3)
     assert ndiff > 0, "the hint changed no launch at this size: the test would be vacuous"
-    assert rel13 <= 2e-4 and ulp <= 2, (rel13, ulp)
+    assert rel13 <= 2e-4 and ulp <= 4 and dmax <= 4e-3, (rel13, ulp, dmax)
     # ---- without the hint the concurrent form IS the one-by-one pass: latents and files bit for bit ------------------
     pipe.latent_cache.write_files = True
     kw = dict(height=H * 8, width=W * 8, num_frames=f, num_inference_steps=2, guidance_scale=1.0, target_fps=8)
