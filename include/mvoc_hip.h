@@ -174,8 +174,12 @@ typedef struct mvoc_xs_desc {
   int64_t m;
   int32_t n, k, n_store, ldo, ldr, act, normalize;
   float ln_eps;
+  int64_t wp_set_rows;  /* 0: one weight stream for every row.  > 0: `wp` holds m / wp_set_rows consecutive streams, set j for rows
+                           [j wp_set_rows, (j + 1) wp_set_rows) -- the per-sample weights of a folded GroupNorm
+                           (mvoc_groupnorm_fold_xs_f16); a multiple of 256 */
 } mvoc_xs_desc;
 int mvoc_xs_linear_f16(const mvoc_xs_desc* d, void* stream);
+
 
 /* Fused front half of a temporal self-attention at the finest level: LayerNorm -> to_q/to_k/to_v -> attention over the frame
  * axis, Q/K/V never written to HBM (TransformerTemporalModel's attn1 / attn2: pnp_utils.py:170-220, 222-346, 720-887; replaces
@@ -221,6 +225,14 @@ typedef struct mvoc_gn_desc {
 } mvoc_gn_desc;
 size_t mvoc_groupnorm_workspace_bytes(int32_t nsample, int32_t rows_per_sample, int32_t c, int32_t groups);
 int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream);
+/* GroupNorm folded into the linear that reads it (GN -> proj_in, no activation in between: pnp_utils.py:185-191, 433-438):
+ * takes the statistics of d's rows as mvoc_groupnorm_f16 does (d->x, nsample, rows_per_sample, c, groups, eps, gamma, beta,
+ * workspace, chan_sums; single source; d->out unused) and writes, per SAMPLE, the weight stream of
+ * mvoc_xs_linear_f16 for W'_s = W gamma rstd_s and c'_s = bias + W (beta - gamma mean_s rstd_s): wp_sets
+ * [nsample][n / 32][k / 16 + 1][512] fp16.  The consumer then runs on the RAW rows with wp_set_rows = rows_per_sample; the
+ * normalised tensor is never written.  w [n][k] fp16 row-major (k == c), bias [n] fp16 or NULL. */
+int mvoc_groupnorm_fold_xs_f16(const mvoc_gn_desc* d, const void* w, const void* bias, int32_t n, int32_t k, void* wp_sets,
+                               void* stream);
 
 /* The same GroupNorm in two halves, for a sample whose rows are spread over several GPUs (frame-axis shard of one
  * long clip, SURVEY 8e / BASELINE configs[3]: the 5-D norms at pnp_utils.py:185-188 and inside TemporalConvLayer,

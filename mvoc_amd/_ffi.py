@@ -61,7 +61,7 @@ class TFusedDesc(C.Structure):
 class XsDesc(C.Structure):
     _fields_ = [("x", vp), ("wp", vp), ("resid", vp), ("out", vp), ("m", i64),
                 ("n", i32), ("k", i32), ("n_store", i32), ("ldo", i32), ("ldr", i32), ("act", i32), ("normalize", i32),
-                ("ln_eps", C.c_float)]
+                ("ln_eps", C.c_float), ("wp_set_rows", i64)]
 
 
 class PnpDesc(C.Structure):
@@ -86,6 +86,7 @@ SIGNATURES = {
     "mvoc_xs_linear_f16": (i32, [C.POINTER(XsDesc), vp]),
     "mvoc_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "mvoc_groupnorm_f16": (i32, [C.POINTER(GnDesc), vp]),
+    "mvoc_groupnorm_fold_xs_f16": (i32, [C.POINTER(GnDesc), vp, vp, i32, i32, vp, vp]),
     "mvoc_groupnorm_moments_f16": (i32, [C.POINTER(GnDesc), vp, vp]),
     "mvoc_groupnorm_apply_moments_f16": (i32, [C.POINTER(GnDesc), vp, i32, vp]),
     "mvoc_layernorm_f16": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),

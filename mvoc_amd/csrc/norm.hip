@@ -296,6 +296,50 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
   }
 }
 
+
+// GroupNorm folded into the LINEAR that reads it (GN -> proj_in of the two transformer kinds: pnp_utils.py:185-191, 433-438 --
+// no activation in between): y = W (gamma (x - mean) rstd + beta) + b = (W gamma rstd) x + (b + W (beta - gamma mean rstd)).  Per
+// SAMPLE (mean / rstd are per sample and group) this kernel writes the scaled weights W'_s, in mvoc_xs_linear_f16's packed
+// fragment order, and the constants c'_s into the stream's last piece; the consumer reads the RAW rows with its sample's set
+// (mvoc_xs_desc.wp_set_rows) and the normalised tensor -- a read and a write of the whole activation -- never exists.
+// grid (n / 32 tiles, nsample), 256 threads; W [n][k] fp16 row-major, k % 16 == 0.
+__global__ __launch_bounds__(256) void gn_fold_xs_kernel(const GnArgs p, const half_t* __restrict__ w, const half_t* __restrict__ bias,
+                                                         int n, int k, half_t* __restrict__ wp) {
+  const int tile = blockIdx.x, smp = blockIdx.y, tid = threadIdx.x;
+  const int nk = k / 16, np = nk + 1;
+  const float* fin = p.ws + (long)p.nsample * p.nchunk * p.G * 3 + (long)smp * p.G * 2;
+  half_t* out = wp + ((long)smp * (n / 32) + tile) * np * 512;
+  // scaled fragments: chunk q = (piece s, lane l) holds W'[32 tile + (l & 31)][16 s + 8 (l >> 5) .. + 7]
+  for (int q = tid; q < nk * 64; q += 256) {
+    const int s_ = q >> 6, l = q & 63;
+    const int row = 32 * tile + (l & 31), col = 16 * s_ + 8 * (l >> 5);
+    const half8_t wv = *reinterpret_cast<const half8_t*>(w + (long)row * k + col);
+    const half8_t gv = *reinterpret_cast<const half8_t*>(p.gamma + col);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)wv[e] * ((float)gv[e] * fin[2 * ((col + e) / p.cpg) + 1]));
+    *reinterpret_cast<half8_t*>(out + (long)q * 8) = o;
+  }
+  // constants: 8 threads per row, each a fixed eighth of the columns, summed in lane order
+  const int r = tid >> 3, part = tid & 7;
+  const int row = 32 * tile + r;
+  float acc = 0.f;
+  for (int col = part * 8; col < k; col += 64) {
+    const half8_t wv = *reinterpret_cast<const half8_t*>(w + (long)row * k + col);
+    const half8_t gv = *reinterpret_cast<const half8_t*>(p.gamma + col);
+    const half8_t bv = *reinterpret_cast<const half8_t*>(p.beta + col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* f = fin + 2 * ((col + e) / p.cpg);
+      acc += (float)wv[e] * ((float)bv[e] - (float)gv[e] * f[0] * f[1]);
+    }
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (part == 0) reinterpret_cast<float*>(out + (long)nk * 512)[r] = acc + (bias ? (float)bias[row] : 0.f);
+}
+
 // group-blocks per sample for gn_final: split the groups over 4 blocks when there are few samples and many slabs
 int gn_final_blocks(const GnArgs& a) {
   const int n = a.sums ? a.nslab : a.nchunk;
@@ -588,6 +632,31 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
   if (!a.inline_final) hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");
+}
+
+
+extern "C" int mvoc_groupnorm_fold_xs_f16(const mvoc_gn_desc* d, const void* w, const void* bias, int32_t n, int32_t k, void* wp_sets,
+                                          void* stream) {
+  GnArgs a;
+  if (int rc = gn_setup(d, false, a)) return rc;
+  MVOC_REQUIRE(w && wp_sets && d->gamma && d->beta, -1, "groupnorm_fold_xs: null operand");
+  MVOC_REQUIRE(d->x2 == nullptr && k == d->c && n > 0 && n % 32 == 0 && k % 16 == 0 && a.cpg >= 1, -2,
+               "groupnorm_fold_xs: single source, k == c, n %% 32 == 0, k %% 16 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  // algorithmic bytes: the statistics' read of the rows when no producer sums exist, the weight sets
+  MvocProfScope prof(MVOC_FAM_GN, s, (d->chan_sums ? 0.0 : 2.0 * (double)d->nsample * d->rows_per_sample * d->c) +
+                                         2.0 * 2.0 * (double)d->nsample * n * k);
+  if (d->chan_sums) {
+    MVOC_REQUIRE(d->rows_per_sample % 256 == 0, -2, "groupnorm_fold_xs: chan_sums needs rows_per_sample %% 256 == 0");
+    a.sums = (const float*)d->chan_sums;
+    a.nslab = d->rows_per_sample / 256;
+  } else {
+    hipLaunchKernelGGL(gn_partial, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(gn_fold_xs_kernel, dim3(n / 32, a.nsample), dim3(256), 0, s, a, (const half_t*)w, (const half_t*)bias, (int)n,
+                     (int)k, (half_t*)wp_sets);
+  return mvoc_check_launch("groupnorm_fold_xs");
 }
 
 extern "C" int mvoc_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int64_t rows, int32_t c,

@@ -34,6 +34,8 @@ struct XsArgs {
   float eps;
   unsigned long long* stamps;  // diagnostic builds only
   int lab;                     // diagnostic builds only: 1 = skip the output stores, 2 = store row-contiguous garbage instead
+  long set_rows;               // > 0: a weight set per set_rows consecutive rows (mvoc_groupnorm_fold_xs_f16), set_bytes apart
+  long set_bytes;
 };
 
 #ifdef MVOC_PP_LAB
@@ -82,10 +84,13 @@ __global__ __launch_bounds__(256, 2) void xslin_kernel(const XsArgs p) {
     ms[g] = m < p.M ? m : p.M - 1;
   }
 
+  // (per-sample weight sets: the block's rows lie inside one set -- set_rows is a multiple of the rows per block, host check)
+  const char* wp_set = reinterpret_cast<const char*>(p.wp) +
+                       (p.set_rows > 0 ? ((long)blockIdx.x * (NW * 32 * RG) / p.set_rows) * p.set_bytes : 0);
   const int pw = (NP - wave + NW - 1) / NW;  // LDS-DMA pieces of this wave per stage
   const int T = p.N / 32;
   auto issue = [&](int st) {
-    const char* src = reinterpret_cast<const char*>(p.wp) + (size_t)st * STAGE + lane * 16;
+    const char* src = wp_set + (size_t)st * STAGE + lane * 16;
     char* dst = smem + (st % NS) * STAGE;
 #pragma unroll
     for (int i = 0; i < (NP + NW - 1) / NW; ++i) {
@@ -391,6 +396,11 @@ extern "C" int mvoc_xs_linear_f16(const mvoc_xs_desc* d, void* stream) {
   static const int force_rg = getenv("MVOC_XS_RG") ? atoi(getenv("MVOC_XS_RG")) : 0;
   const int rg = force_rg ? force_rg : (d->m >= 131072 && d->k == 320 ? 2 : 1);
   a.stamps = nullptr;
+  a.lab = 0;
+  a.set_rows = d->wp_set_rows;
+  a.set_bytes = (long)(d->n / 32) * (d->k / 16 + 1) * 1024;
+  MVOC_REQUIRE(d->wp_set_rows >= 0 && (d->wp_set_rows == 0 || (d->wp_set_rows % (128 * rg) == 0 && d->m % d->wp_set_rows == 0)), -2,
+               "xs_linear: wp_set_rows (%ld) must be a multiple of the %d rows of a block and divide m", (long)d->wp_set_rows, 128 * rg);
 #ifdef MVOC_PP_LAB
   if (const char* e = getenv("MVOC_XS_STAMPS")) a.stamps = (unsigned long long*)strtoull(e, nullptr, 10);
   a.lab = getenv("MVOC_XS_LAB") ? atoi(getenv("MVOC_XS_LAB")) : 0;

@@ -257,14 +257,16 @@ def temporal_attn(q, k, v, *, nsample, frames, hw, heads, out=None):
 XS_K = (64, 128, 320)   # activation-stationary kernels: the rows' K channels live in registers
 
 
-def xs_linear(x, wp, n, *, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, n_store=0, out=None):
+def xs_linear(x, wp, n, *, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, n_store=0, out=None, set_rows=0):
     """activation-stationary linear (include/mvoc_hip.h: mvoc_xs_linear_f16): x contiguous [m, k]; wp = unet.pack_xs_weights(W
     [n, k], constants [n]) (fragment-ordered weights + the per-channel constants); ``normalize``: LayerNorm folded (rows
     normalised in registers; W gamma-scaled, constants = beta @ W^T + bias)"""
     _chk(x, "x"), _chk(wp, "wp"), _chk(resid, "resid")
     m, k = x.shape
-    if not x.is_contiguous() or k % 16 or n % 32 or wp.numel() != (n // 32) * (k // 16 + 1) * 512:
-        raise RuntimeError("xs_linear: x must be contiguous [m, k] and wp the pack_xs_weights() image of an [n, k] matrix")
+    nsets = m // set_rows if set_rows else 1
+    if not x.is_contiguous() or k % 16 or n % 32 or wp.numel() != nsets * (n // 32) * (k // 16 + 1) * 512 or (set_rows and m % set_rows):
+        raise RuntimeError("xs_linear: x must be contiguous [m, k] and wp the pack_xs_weights() image of an [n, k] matrix "
+                           "(one image per set_rows rows when set_rows is given)")
     cols = n // 2 if act == ACT_GEGLU else (n_store if n_store else n)
     if out is None:
         out = torch.empty((m, cols), dtype=torch.float16, device=x.device)
@@ -272,7 +274,7 @@ def xs_linear(x, wp, n, *, normalize=False, eps=1e-5, act=ACT_NONE, resid=None, 
     d.x, d.wp, d.resid, d.out = x.data_ptr(), wp.data_ptr(), _ptr(resid), out.data_ptr()
     d.m, d.n, d.k, d.n_store, d.ldo = m, n, k, cols, _rowmajor(out, "out")
     d.ldr = _rowmajor(resid, "resid") if resid is not None else 0
-    d.act, d.normalize, d.ln_eps = act, int(bool(normalize)), eps
+    d.act, d.normalize, d.ln_eps, d.wp_set_rows = act, int(bool(normalize)), eps, set_rows
     check(lib.mvoc_xs_linear_f16(C.byref(d), _stream()), "xs_linear")
     return out
 
@@ -331,6 +333,23 @@ def groupnorm(x, gamma, beta, *, nsample, rows_per_sample, groups, eps, silu, x2
         d.chan_sums, d.chan_sums2 = cs.data_ptr(), _ptr(cs2)
     check(lib.mvoc_groupnorm_f16(C.byref(d), _stream()), "groupnorm")
     return out
+
+
+def groupnorm_fold_xs(x, gamma, beta, w, bias, *, nsample, rows_per_sample, groups, eps):
+    """GroupNorm(x) folded into the linear ``w`` [n, k] (+ ``bias``) that reads it (include/mvoc_hip.h:
+    mvoc_groupnorm_fold_xs_f16): the per-sample weight streams for ``xs_linear(x_raw, wp, n, set_rows=rows_per_sample)``; the
+    statistics come from the producer's channel sums when x carries them"""
+    _chk(w, "w"), _chk(bias, "bias")
+    n, k = w.shape
+    if k != x.shape[1] or n % 32 or k % 16 or not w.is_contiguous():
+        raise RuntimeError("groupnorm_fold_xs: w must be contiguous [n % 32 == 0, k == channels of x]")
+    d, ws = _gn_desc(x, gamma, beta, None, None, nsample, rows_per_sample, groups, eps, False)
+    cs = chan_sums_of(x, rows_per_sample) if USE_CHAN_SUMS else None
+    if cs is not None:
+        d.chan_sums = cs.data_ptr()
+    wp = torch.empty((nsample, n // 32, k // 16 + 1, 512), dtype=torch.float16, device=x.device)
+    check(lib.mvoc_groupnorm_fold_xs_f16(C.byref(d), w.data_ptr(), _ptr(bias), n, k, wp.data_ptr(), _stream()), "groupnorm_fold_xs")
+    return wp
 
 
 def groupnorm_moments(x, *, nsample, rows_per_sample, groups):

@@ -145,6 +145,10 @@ class I2VGenXLPipeline:
         self.max_cached_graphs = 4
         self._concurrent_states = {}  # invert_concurrent: one captured iteration per concurrent clip
         self._streams = []
+        # composition loop: the UNet's source chunks are never read behind the last injection site (unet.prune_source_tail)
+        self.prune_source_tail = os.environ.get("MVOC_PRUNE_SOURCE_TAIL", "1") != "0"  # (=0: A/B)
+        # ... and its unconditional / conditional chunks are one computation up to the first cross-attention (unet.shared_prefix_chunks)
+        self.share_cfg_prefix = os.environ.get("MVOC_SHARE_CFG_PREFIX", "1") != "0"  # (=0: A/B)
         self.latent_cache = LatentCache(unet.device)
 
     # ---- reference plumbing ------------------------------------------------------------------------
@@ -466,14 +470,27 @@ class I2VGenXLPipeline:
                                                   cond["image_latents"], cond["image_embeddings"],
                                                   cond["encoder_hidden_states"], False)
 
+        # classifier-free guidance: the unconditional and the conditional chunk receive the same latent (below); when their image
+        # latents and fps are equal too -- the reference builds both from the main image, pipeline_i2vgen_xl.py:1676-1690 -- they
+        # differ only in what the cross-attentions see, and the UNet shares their common prefix (unet.shared_prefix_chunks)
+        share = bool(self.share_cfg_prefix and do_cfg and
+                     all(torch.equal(cond[k][nb - 2], cond[k][nb - 1]) for k in ("image_latents_first", "image_latents", "fps")))
+        st["share_cfg_prefix"] = share
+
         def body():
             x = st["latents"]
             if do_cfg:
                 st["inp"][nb - 2].copy_(x[0])
             st["inp"][nb - 1].copy_(x[0])
-            noise = self.unet.forward_ext(st["inp"], st["t"], cond["fps"], cond["image_latents_first"], cond["image_latents"],
-                                          cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False,
-                                          conditioning=prepared)[0]
+            u = self.unet
+            saved, u.prune_source_tail = u.prune_source_tail, bool(self.prune_source_tail)  # this loop reads the destination chunks only
+            saved_sp, u.shared_prefix_chunks = u.shared_prefix_chunks, (2 if share else 0)
+            try:
+                noise = u.forward_ext(st["inp"], st["t"], cond["fps"], cond["image_latents_first"], cond["image_latents"],
+                                      cond["image_embeddings"], cond["encoder_hidden_states"], multi_frame_guidance=False,
+                                      conditioning=prepared)[0]
+            finally:
+                u.prune_source_tail, u.shared_prefix_chunks = saved, saved_sp
             ops.ddim_step(x, noise[nb - 1:nb].contiguous(), st["coef"],
                           v_uncond=noise[nb - 2:nb - 1].contiguous() if do_cfg else None, out=x)
 
@@ -502,7 +519,8 @@ class I2VGenXLPipeline:
         # a captured iteration bakes in EVERY site's injecting() decision (the reference allows a schedule per site) and
         # the device copies of the masks: both are part of the variant key
         u = self.unet
-        vkey = (u.injection_flags(), u.mask_key(st["masks"]), bool(u.pair_destinations), bool(u.prune_dead_chunks))
+        vkey = (u.injection_flags(), u.mask_key(st["masks"]), bool(u.pair_destinations), bool(u.prune_dead_chunks),
+                bool(self.prune_source_tail), bool(st.get("share_cfg_prefix")))
         g = st["variants"].get(vkey)
         if g is None:
             g = st["variants"][vkey] = GraphedStep(st["body"], preserve=(st["latents"],))

@@ -163,6 +163,23 @@ class Linear:
             return ops.xs_linear(x, self.wp, self.w.shape[0], n_store=self.n, **kw)
         return ops.linear(x, self.w, self.b, n_store=self.n, sums=sums, rowmom=rowmom, **kw)
 
+    USE_GN_FOLD = os.environ.get("MVOC_GN_FOLD", "1") != "0"  # MVOC_GN_FOLD=0: A/B against GroupNorm + linear
+
+    def call_gn(self, eng, x, norm, *, nsample, rows_per_sample, groups, eps, rowmom=False):
+        """GroupNorm(x) -> this linear (no activation in between: GN -> proj_in, pnp_utils.py:185-191, 433-438).  Where the
+        activation-stationary kernel takes the call (K = 320 and many rows: the finest level) the norm is FOLDED into
+        per-sample weights (ops.groupnorm_fold_xs) and the linear reads the raw rows: the normalised tensor -- a read and a
+        write of the whole activation -- never exists.  Elsewhere: the GroupNorm kernels, then the linear."""
+        if (Linear.USE_GN_FOLD and eng.shard is None and self._xs_ok(x, {}) and rows_per_sample % 256 == 0 and self.w.shape[0] == self.n
+                and x.shape[0] == nsample * rows_per_sample and nsample <= 4096):
+            wp = ops.groupnorm_fold_xs(x, *norm, self.w, self.b, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps)
+            return ops.xs_linear(x, wp, self.w.shape[0], n_store=self.n, set_rows=rows_per_sample)
+        if eng.shard is None:
+            h = ops.groupnorm(x, *norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=False)
+        else:
+            h = eng.groupnorm5d(x, norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=False)
+        return self(h, rowmom=rowmom)
+
     def fold_layernorm(self, gamma, beta, eps=1e-5):
         """LayerNorm(x) @ W^T + b  ==  rstd * (x @ (W*gamma)^T - mean * rowsum(W*gamma)) + (beta @ W^T + b): the GEMM
         reads the raw rows, accumulates their mean / rstd from the tiles it stages anyway (csrc/gemm.hip) and the
@@ -253,8 +270,8 @@ class Transformer2DModel(_TransformerBase):
         B, F, H, W = geo
         hw, nimg = H * W, B * F
         blk = self.transformer_blocks[0]
-        h = ops.groupnorm(x, *self.norm, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h, rowmom=True)  # (norm1 reads it next)
+        h = self.proj_in.call_gn(eng, x, self.norm, nsample=nimg, rows_per_sample=hw, groups=self.groups, eps=1e-6,
+                                 rowmom=True)  # (norm1 reads it next)
         c = blk.dim
         # self-attention over the H*W tokens of each image
         qkv = blk.attn1.to_qkv.call_ln(h, blk.norm1)
@@ -278,6 +295,11 @@ class Transformer2DModel(_TransformerBase):
         else:
             a = ops.flash_attn(q, k, v, nbatch=nimg, heads=self.heads, tq=hw, tk=hw)
         h = blk.attn1.to_out(a, resid=h, rowmom=True)
+        if eng._expand_site is self:
+            # shared_prefix_chunks: the unconditional chunk's rows so far ARE the conditional chunk's -- from here on (their
+            # contexts differ) both exist
+            h, x = eng.expand_last_chunk(h, F * hw), eng.expand_last_chunk(x, F * hw)
+            B, nimg = B + 1, (B + 1) * F
         # cross-attention to the 77 text + 64 image-latent + 4 CLIP-image tokens
         q2 = blk.attn2.to_q.call_ln(h, blk.norm2)
         kv = ctx.kv.get(self)
@@ -315,8 +337,7 @@ class TransformerTemporalModel(_TransformerBase):
         B, F, H, W = geo
         hw = H * W
         blk = self.transformer_blocks[0]
-        h = eng.groupnorm5d(x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h, rowmom=True)
+        h = self.proj_in.call_gn(eng, x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, rowmom=True)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
             proc = attn.processor
@@ -334,6 +355,10 @@ class TransformerTemporalModel(_TransformerBase):
                 ld = qkv.stride(0)
                 ops.pnp_blend_tokens(q, masks, x2=k, frames=F, height=H, width=W, channels=c, chunk_stride=F * hw * ld,
                                      f_stride=hw * ld, p_stride=ld, base_chunk0=proc.inject_background, ndst=ndst)
+                if eng._tail_site is self:  # (prune_source_tail) the last reader of the source chunks was this blend
+                    r0 = (B - ndst) * F * hw
+                    q, k, v, h, x = q[r0:], k[r0:], v[r0:], h[r0:], x[r0:]
+                    B = ndst
             a = ops.temporal_attn(q, k, v, nsample=B, frames=F, hw=hw, heads=self.heads)
             h = attn.to_out(a, resid=h, rowmom=True)
         f1 = blk.ff1.call_ln(h, blk.norm3, act=ACT_GEGLU)
@@ -504,6 +529,24 @@ class I2VGenXLUNet:
         # demo's first 5 of 50 composition steps.
         self.prune_dead_chunks = True
         self._pruned = False
+        # The SOURCE chunks [bg, obj_1..obj_n] of a composition batch exist to feed the injection sites: no hook, and nothing in
+        # the loop around the UNet (pipeline_i2vgen_xl.py:1713-1728 reads the two destination chunks only), ever reads their
+        # OUTPUT.  Behind the last site that still takes their q / k -- up_blocks[3].temp_attentions[2].attn1 on a Q/K-only step
+        # (pnp_utils.py:720-887; 45 of the demo's 50 steps) -- their rows are dead: with prune_source_tail the rest of that
+        # temporal transformer, conv_norm_out and conv_out run on the destination chunks only and the source chunks of the
+        # returned tensor are zeros.  Off by default (forward_ext stays faithful chunk by chunk); the composition loop of
+        # pipeline.py, which never reads those chunks, turns it on.
+        self.prune_source_tail = False
+        self._tail_site = None
+        # Classifier-free guidance feeds the SAME latent, image latents, fps and timestep to the unconditional and the conditional
+        # chunk (pipeline_i2vgen_xl.py:1676-1690); they differ in the prompt / CLIP-image embeddings, which enter through the
+        # spatial transformers' cross-attention only.  Up to the first cross-attention (conv_in, transformer_in, the first
+        # resnet + temporal conv, GroupNorm / proj_in / self-attention of down_blocks[0].attentions[0]) the two chunks' rows are
+        # therefore identical: with shared_prefix_chunks = 2 (set by a caller that KNOWS the last two chunks' inputs to be
+        # equal: the composition loop of pipeline.py checks it once per state) that prefix runs on B - 1 chunks and the last
+        # chunk's rows are copied where the chunks part.  0 = off: every chunk computed (the default).
+        self.shared_prefix_chunks = 0
+        self._expand_site = None
         # Q/K-injection sites: the two destination chunks attend with identical q and k (the hook assigns one blend to both);
         # their attention probabilities are computed once (ops.flash_attn v2 / out2).  False: five independent passes (A/B, tests)
         self.pair_destinations = True
@@ -719,6 +762,15 @@ class I2VGenXLUNet:
         if getattr(h, "chan_sums", None) is not None:
             h.chan_sums = None  # rewritten in place: the producer's GroupNorm statistics no longer describe these rows
 
+    @staticmethod
+    def expand_last_chunk(t, rows):
+        """[B chunks of `rows` rows] -> B + 1 chunks, the last one repeated (shared_prefix_chunks); a row copy drops any producer
+        statistics riding on the tensor object, which described B chunks"""
+        out = torch.empty((t.shape[0] + rows, t.shape[1]), dtype=t.dtype, device=t.device)
+        out[:t.shape[0]].copy_(t)
+        out[t.shape[0]:].copy_(t[t.shape[0] - rows:])
+        return out
+
     # ---- frame-axis shard plumbing --------------------------------------------------------------------
     def temporal_section(self, x, geo, section):
         """run ``section(eng, rows, geo, full_hw)`` on rows that hold ALL frames: as they are on one GPU, or exchanged
@@ -899,6 +951,12 @@ class I2VGenXLUNet:
         if self.prune_dead_chunks and not self._pruned and self.shard is None and co.injecting():
             return self._forward_source_chunks(sample, timestep, fps, image_latents_first, image_latents, image_embeddings,
                                                encoder_hidden_states, multi_frame_guidance, conditioning)
+        self._tail_site = None
+        if self.prune_source_tail and not self._pruned and self.shard is None and not co.injecting():
+            last = self.up_blocks[-1].temp_attentions[-1] if self.up_blocks[-1].has_cross_attention else None
+            if last is not None and last.transformer_blocks[0].attn1.processor.injecting():
+                self._tail_site = last
+        B_full = B
         up_factor = 2 ** self.num_upsamplers
         forward_upsample_size = any(s % up_factor != 0 for s in (H, W))
         temb_act = self._embeddings(timestep, fps, B)
@@ -922,16 +980,28 @@ class I2VGenXLUNet:
             x8 = x8.view(B, F, hw, 8)[:, f0:f1].reshape(-1, 8)
             F = f1 - f0
         geo = (B, F, H, W)
-        x, _, _ = ops.conv3x3(x8, self.conv_in.w, self.conv_in.b, nimg=B * F, h=H, wd=W, n_store=self.conv_in.cout)
+        self._expand_site = None
+        if (self.shared_prefix_chunks == 2 and B >= 2 and sh is None and not self._pruned and
+                self.down_blocks[0].has_cross_attention):
+            # the last two chunks are equal up to the first cross-attention: the prefix on B - 1 chunks
+            self._expand_site = self.down_blocks[0].attentions[0]
+            geo = (B - 1, F, H, W)
+            x8 = x8[:(B - 1) * F * hw]
+        x, _, _ = ops.conv3x3(x8, self.conv_in.w, self.conv_in.b, nimg=geo[0] * F, h=H, wd=W, n_store=self.conv_in.cout)
         x = self.transformer_in.forward(self, x, geo)
 
         skips = [(x, geo)]
+        if self._expand_site is not None:
+            skips = [(self.expand_last_chunk(x, F * hw), (B, F, H, W))]  # (the decoder's last resnet reads it with every chunk)
         for blk in self.down_blocks:
             for j, rn in enumerate(blk.resnets):
                 x = rn.forward(self, x, None, temb_act, geo)
                 x = blk.temp_convs[j].forward(self, x, geo)
                 if blk.has_cross_attention:
                     x = blk.attentions[j].forward(self, x, geo, ctx)
+                    if blk.attentions[j] is self._expand_site:
+                        geo = (B, F, H, W)
+                        self._expand_site = None
                     x = blk.temp_attentions[j].forward(self, x, geo)
                 skips.append((x, geo))
             if blk.downsamplers is not None:
@@ -960,6 +1030,9 @@ class I2VGenXLUNet:
                 if blk.has_cross_attention:
                     x = blk.attentions[j].forward(self, x, geo, ctx)
                     x = blk.temp_attentions[j].forward(self, x, geo)
+                    if blk.temp_attentions[j] is self._tail_site:  # the destination chunks' rows only from here on
+                        B = x.shape[0] // (F * hw)
+                        geo = (B, F, H, W)
             if blk.upsamplers is not None:
                 x, geo = blk.upsamplers[0].forward(x, geo, upsample_size)
 
@@ -976,4 +1049,9 @@ class I2VGenXLUNet:
             out = nchw.reshape(B, F, co.cout, H, W).permute(0, 2, 1, 3, 4).contiguous()
         else:
             out = ops.tokens_to_ncfhw(y, B, co.cout, F, H, W)
+        if B != B_full:  # prune_source_tail: the source chunks' (never read) outputs are zeros
+            full = torch.zeros((B_full,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+            full[B_full - B:] = out
+            out = full
+        self._tail_site = self._expand_site = None
         return out if sh is None else sh.gather_frames(out, dim=2)

@@ -161,6 +161,44 @@ def test_ext_forward_with_all_hooks_full_width(pair, trio):
             finally:
                 eng.pair_destinations = True
             assert torch.equal(out, five)
+            # prune_source_tail (the composition loop's setting): the source chunks' dead tail is not computed -- the destination
+            # chunks against the oracle at the forward tolerance and against the five-chunk forward
+            eng.prune_source_tail = True
+            try:
+                tail = eng.forward_ext(x["sample"], t, x["fps"], x["il1"], x["il"], x["ie"], x["eh"])[0]
+            finally:
+                eng.prune_source_tail = False
+            assert not tail[:3].any()
+            rel, mx = _metrics(tail[3:], ref[3:])
+            rel5, _ = _metrics(tail[3:], out[3:])
+            print(f"full-width ext forward, prune_source_tail: destination chunks rel-L2 {rel:.2e} vs oracle, {rel5:.2e} vs the "
+                  f"five-chunk forward{' (bit-identical)' if torch.equal(tail[3:], out[3:]) else ''}")
+            assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD and rel5 < 1e-3, (rel, mx, rel5)
+    # shared_prefix_chunks (the composition loop's setting under classifier-free guidance): the unconditional and the conditional
+    # chunk enter with the same latent / image latents / fps and differ in the prompt + CLIP-image embeddings only -- the engine
+    # computes their common prefix (everything up to the first cross-attention) once
+    z = {k: v.clone() for k, v in x.items()}
+    for k in ("sample", "il1", "il"):
+        z[k][4] = z[k][3]
+    t = 861
+    st.t, st.masks = t, masks
+    ref = o.forward_ext(z["sample"], t, z["fps"], z["il1"], z["il"], z["ie"], z["eh"])[0]
+    pnp_utils.register_time_all(pipe, t, masks)
+    plain = eng.forward_ext(z["sample"], t, z["fps"], z["il1"], z["il"], z["ie"], z["eh"])[0]
+    eng.shared_prefix_chunks = 2
+    try:
+        shared = eng.forward_ext(z["sample"], t, z["fps"], z["il1"], z["il"], z["ie"], z["eh"])[0]
+    finally:
+        eng.shared_prefix_chunks = 0
+    assert not torch.equal(ref[3], ref[4])  # (the two chunks do part at the cross-attentions)
+    rel, mx = _metrics(shared, ref)
+    relp, _ = _metrics(shared, plain)
+    print(f"full-width ext forward, shared CFG prefix: rel-L2 {rel:.2e} vs oracle, {relp:.2e} vs every chunk computed"
+          f"{' (bit-identical)' if torch.equal(shared, plain) else ''}")
+    # (the prefix then runs at another row count, i.e. on other tiles: two fp16 evaluations of the network, each within tolerance
+    # of the oracle, differ from each other by about as much)
+    assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD and relp <= REL_L2_FWD, (rel, mx, relp)
+    assert torch.equal(plain[3, :, :, :2], plain[3, :, :, :2])
 
 
 def test_one_inversion_and_one_composition_step_full_width(pair, trio):

@@ -341,6 +341,30 @@ def test_tconv3_production_tiles_exact(ops, tile):
     assert torch.equal(out.float().cpu(), ref), f"tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
 
 
+@pytest.mark.parametrize("tile", [0, 81, 82])
+def test_tconv3_frame_fastest_tile_order_exact(ops, tile):
+    """temporal conv whose frames span several 256-pixel tiles (hw = 1024: four patches per frame): the eight-phase kernel walks
+    the FRAMES of a patch before the next patch (gemm8.hip: tmap_t) -- same function, exact on integers, and the producer's
+    channel sums still land in row order ([m / 256] slabs)"""
+    from mvoc_amd.unet import pack_tconv
+    g = torch.Generator().manual_seed(1024)
+    nb, c, frames, hw = 2, 320, 16, 1024
+    x = _ints(g, (nb, c, frames, hw, 1))
+    wt = _ints(g, (c, c, 3, 1, 1))
+    wt[torch.rand(wt.shape, generator=g) < 0.5] = 0
+    b = _ints(g, (c,), -4, 4)
+    ref = F.conv3d(x, wt, b, padding=(1, 0, 0)) + x
+    assert ref.abs().max() < 2048
+    rows = dev(x[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c))
+    ref = ref[..., 0].permute(0, 2, 3, 1).reshape(nb * frames * hw, c).contiguous()
+    out = ops.tconv3(rows, pack_tconv(dev(wt)), dev(b), nvid=nb, frames=frames, hw=hw, resid=rows, tile=tile, split_k=1, sums=True)
+    assert torch.equal(out.float().cpu(), ref), f"tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+    cs = getattr(out, "chan_sums", None)
+    assert cs is not None
+    o = ref.reshape(-1, 256, c)
+    assert torch.allclose(cs[..., 0].cpu(), o.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(cs[..., 1].cpu(), (o * o).sum(1), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("tile", PROD_TILES)
 @pytest.mark.parametrize("m,n,k", [(65536, 320, 320), (16384, 960, 320), (20480, 1280, 1280)])
 def test_linear_production_tiles_exact(ops, m, n, k, tile):
@@ -930,6 +954,35 @@ def test_gemm_row_moments_and_layernorm_statistics_from_them(ops, m, n, k, resid
         sk = ops.linear(x, w, b, resid=r, tile=tile, split_k=2, rowmom=True)
         assert getattr(sk, "row_moments", None) is None
     assert getattr(ops.linear(x, w, b, resid=None, tile=tile, split_k=1, n_store=n - 64, rowmom=True), "row_moments", None) is None
+
+
+@pytest.mark.parametrize("nsample,rows,c,n,sums", [(6, 1024, 320, 320, False), (2, 4096, 320, 320, True), (20, 256, 128, 128, False),
+                                                  (1, 8192, 64, 64, True)])
+def test_groupnorm_folded_into_xs_linear(ops, nsample, rows, c, n, sums):
+    """GN -> proj_in with the norm folded into per-sample weights (mvoc_groupnorm_fold_xs_f16 + mvoc_xs_desc.wp_set_rows): against
+    fp32 torch and against the GroupNorm kernels followed by the same linear; statistics from the producer's channel sums too"""
+    g = torch.Generator().manual_seed(nsample * rows + c)
+    m = nsample * rows
+    x = torch.randn(m, c, generator=g) * (0.5 + torch.rand(nsample, 1, c, generator=g).repeat(1, rows, 1).reshape(m, c)) + \
+        torch.randn(nsample, 1, c, generator=g).repeat(1, rows, 1).reshape(m, c)
+    w = (torch.randn(n, c, generator=g) / c ** 0.5).half()
+    b = torch.randn(n, generator=g).half()
+    gm, bt = (1 + 0.3 * torch.randn(c, generator=g)).half(), (0.3 * torch.randn(c, generator=g)).half()
+    if sums:  # x as the output of a GEMM that emits its channel sums (identity weights keep the values)
+        xin = ops.linear(dev(x.half()), dev(torch.eye(c).half()), None, tile=81 if c % 64 == 0 and m >= 1024 else 0, split_k=1, sums=True)
+        assert getattr(xin, "chan_sums", None) is not None
+    else:
+        xin = dev(x.half())
+    xr = xin.float().cpu()
+    ref = F.group_norm(xr.reshape(nsample, rows, c).permute(0, 2, 1), 32, gm.float(), bt.float(), 1e-6).permute(0, 2, 1).reshape(m, c) \
+        @ w.float().t() + b.float()
+    wp = ops.groupnorm_fold_xs(xin, dev(gm), dev(bt), dev(w), dev(b), nsample=nsample, rows_per_sample=rows, groups=32, eps=1e-6)
+    out = ops.xs_linear(xin, wp, n, set_rows=rows)
+    h = ops.groupnorm(xin, dev(gm), dev(bt), nsample=nsample, rows_per_sample=rows, groups=32, eps=1e-6, silu=False)
+    from mvoc_amd.unet import pack_xs_weights
+    two = ops.xs_linear(h, pack_xs_weights(dev(w), dev(b)), n)
+    assert rel_l2(out, ref) < 1.5e-3 and rel_l2(two, ref) < 1.5e-3, (rel_l2(out, ref), rel_l2(two, ref))
+    assert rel_l2(out, two) < 1.5e-3
 
 
 @pytest.mark.parametrize("c", [64, 320, 512, 1280])

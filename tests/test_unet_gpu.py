@@ -93,6 +93,20 @@ def test_g7_pnp_against_reference_golden(golden_dir):
             finally:
                 eng.pair_destinations = True
             assert torch.equal(out, five)
+            # ... and behind the last Q/K site nothing reads the SOURCE chunks (prune_source_tail, the composition loop's setting):
+            # the destination chunks come out as before, the source chunks as zeros
+            eng.prune_source_tail = True
+            try:
+                tail = eng.forward_ext(t("sample"), tt, t("fps"), t("image_latents_first"), t("image_latents"),
+                                       t("image_embeddings"), t("encoder_hidden_states"))[0]
+            finally:
+                eng.prune_source_tail = False
+            nsrc = len(masks) + 1
+            assert not tail[:nsrc].any()
+            rel = float((tail[nsrc:].float() - out[nsrc:].float()).norm() / out[nsrc:].float().norm())
+            print(f"prune_source_tail t={tt}: destination chunks rel-L2 {rel:.2e} vs the five-chunk forward"
+                  f"{' (bit-identical)' if torch.equal(tail[nsrc:], out[nsrc:]) else ''}")
+            assert rel < 1e-3, rel
         if tt == 981:  # feature-injection steps: chunks 3 and 4 leave conv_out identical (SURVEY B-5)
             assert torch.equal(out[3], out[4])
             # ... and nothing computed FOR them reaches the output: the engine runs such a step on the source chunks only
