@@ -56,7 +56,13 @@ typedef struct mvoc_gemm_desc {
   int32_t c1;           /* channels taken from `a` per tap (rest from a2); == cin when a2 == NULL */
   int32_t cin;          /* conv / temporal: channels per tap (c1 + c2); plain: == k */
   /* conv3x3 (pad 1): output pixel grid [nimg][hout][wout]; source image [hsrc][wsrc]; if upsample != 0 the
-   * conv runs on the nearest-upsampled [hup][wup] view of the source (Upsample2D folded into the gather) */
+   * conv runs on the nearest-upsampled [hup][wup] view of the source (Upsample2D folded into the gather).
+   * upsample == 2: the SUB-PIXEL form of an exact 2x upsample (hup == 2 hsrc, wup == 2 wsrc): the three taps of a row of the 3 x 3
+   * kernel fall on only two source rows (columns likewise), so per output parity (a, b) the conv is a 2 x 2 conv on the source
+   * image -- 4 taps of matrix work instead of 9.  `w` then holds the four parity kernels [4 = 2 a + b][n][dy][dx][cin] (k = 4 cin,
+   * tap (dy, dx) of parity a: dy = 0 <- ky 0, dy = 1 <- ky 1 + ky 2 for a = 0; dy = 0 <- ky 0 + ky 1, dy = 1 <- ky 2 for a = 1; columns
+   * likewise: mvoc_amd.unet.pack_conv3x3_subpixel) and the source pixel (i, j) of parity (a, b) is output pixel (2 i + a, 2 j + b).
+   * Plain epilogue (bias) only, one source, nimg hsrc wsrc a multiple of 256, no split-K, no chan_sums. */
   int32_t nimg, hout, wout, hsrc, wsrc, stride, upsample, hup, wup;
   /* temporal3 (pad 1 over frames): rows are [nvid][frames][hw] */
   int32_t frames, hw;

@@ -925,8 +925,22 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   if (d->a_mode == MVOC_A_CONV3X3) {
     MVOC_REQUIRE(d->nimg > 0 && d->hout > 0 && d->wout > 0 && d->hsrc > 0 && d->wsrc > 0, -1, "gemm: conv dims");
     MVOC_REQUIRE((int64_t)d->nimg * d->hout * d->wout == d->m, -1, "gemm: conv m != nimg*hout*wout");
-    MVOC_REQUIRE(d->k >= 9 * (int64_t)d->cin, -1, "gemm: conv k < 9*cin");
+    MVOC_REQUIRE(d->upsample == 2 || d->k >= 9 * (int64_t)d->cin, -1, "gemm: conv k < 9*cin");
     MVOC_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && !d->upsample), -1, "gemm: pad_mode %d", d->pad_mode);
+    if (d->upsample == 2) {
+      // sub-pixel form of Upsample2D + conv (gemm_args.h: subpx): per output parity a 2 x 2 conv on the source image with the
+      // caller's four summed kernels w [4][n][4 cin] -- 4 taps of MFMA work instead of 9.  Eight-phase tiles only.
+      const int64_t spr = (int64_t)d->nimg * d->hsrc * d->wsrc;
+      MVOC_REQUIRE(d->hup == 2 * d->hsrc && d->wup == 2 * d->wsrc && d->hout == d->hup && d->wout == d->wup && d->stride <= 1 &&
+                       d->k == 4 * (int64_t)d->cin && spr % 256 == 0 && d->a2 == nullptr && d->resid == nullptr && d->rowadd == nullptr &&
+                       d->act == MVOC_ACT_NONE && !d->ln_rowsum && d->split_k <= 1 && d->m >= 1024 && (d->tile == 0 || d->tile == 81),
+                   -2, "gemm: upsample == 2 (sub-pixel) needs an exact 2x upsample, k == 4 cin, one source, nimg * hsrc * wsrc %% 256 == 0, "
+                       "the plain epilogue, no split-K and m >= 1024");
+      a.subpx = 1;
+      a.sp_rows = (int)spr;
+      a.hout = d->hsrc; a.wout = d->wsrc;  // the row grid of a phase is the SOURCE grid
+      a.hup = d->hsrc; a.wup = d->wsrc;    // ... and so are the bounds the taps are tested against
+    }
   } else if (d->a_mode == MVOC_A_TEMPORAL3) {
     MVOC_REQUIRE(d->frames > 0 && d->hw > 0 && d->m % ((int64_t)d->frames * d->hw) == 0, -1, "gemm: temporal dims");
     MVOC_REQUIRE(d->k == 3 * (int64_t)d->cin, -1, "gemm: temporal k != 3*cin");
@@ -941,7 +955,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
   const double flops = 2.0 * (double)d->m * (double)d->n * (double)d->k;
   MvocProfScope prof(MVOC_FAM_GEMM, s, flops);
   const bool glds_ok = d->k % 64 == 0 && d->cin % 64 == 0 && d->c1 % 64 == 0 &&
-                       (d->a_mode != MVOC_A_CONV3X3 || d->k == 9 * (int64_t)d->cin);
+                       (d->a_mode != MVOC_A_CONV3X3 || d->k == (d->upsample == 2 ? 4 : 9) * (int64_t)d->cin);
   if (d->ln_rowsum) {
     MVOC_REQUIRE(d->ln_bias && d->ln_stats && glds_ok && d->a_mode == MVOC_A_PLAIN && d->a2 == nullptr && d->split_k <= 1 &&
                      (d->tile == 0 || d->tile >= 11),
@@ -966,6 +980,10 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                      // 5 row-add rows per 256-row tile
                      ((uintptr_t)d->bias & 15) == 0 && ((uintptr_t)d->ln_rowsum & 15) == 0 && ((uintptr_t)d->ln_bias & 15) == 0 &&
                      (!d->rowadd || (((uintptr_t)d->rowadd & 15) == 0 && d->ld_rowadd % 8 == 0 && a.rowadd_div >= 64));
+  if (a.subpx) {
+    MVOC_REQUIRE(g8_ok, -2, "gemm: the sub-pixel upsample conv runs on the eight-phase tiles only (k, cin %% 64 == 0, 16-byte addressable output)");
+    tile = 81;
+  }
   if (tile == 0 && g8_ok && d->m >= 1024 && d->k >= 256) {
     // Measured (tools/gemm_bench.py, B = 1 and B = 5 shape sets, profiles/r3/): the eight-phase tiles win wherever their grid
     // fills the chip; what decides between them and against the general tiles is quantisation -- channels wasted in the last
@@ -1081,7 +1099,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
           a.split_k = d->split_k; a.k_per_split = (int)(d->k / d->split_k); a.ws = (float*)d->workspace;
         }
       }
-      if (d->chan_sums && a.split_k == 1 && d->act == MVOC_ACT_NONE && a.M % 256 == 0) {  // statistics of the stored tile from the epilogue
+      if (d->chan_sums && a.split_k == 1 && d->act == MVOC_ACT_NONE && a.M % 256 == 0 && !a.subpx) {  // statistics of the stored tile from the epilogue
         // (whole 256-row tiles only: stats_pass sums the tile as it stands in LDS, phantom rows >= M included)
         a.stats = (float*)d->chan_sums;
         g_sums_written = 1;

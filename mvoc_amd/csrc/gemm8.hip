@@ -163,7 +163,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const int cch = (pos ^ ((4 * wave + (lrow >> 1)) & 7)) * 8;  // source chunk (halfs): swizzle of row 8 (wave + 8 q) + lrow
   // weight side: one byte offset per staged row of X half 0 (half 1 = + XQ rows); the K advance lives in the scalar
   // offset; rows >= N fall outside the resource (num_records = N K 2 bytes) and read zeros
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((size_t)p.N * p.K * 2), 0x00020000);
+  // sub-pixel upsample conv (UPS instantiation only): the tile's output parity; its weights are phase `sp_ph` of four kernels
+  int sp_ph = 0;
+  if constexpr (UPS) {
+    if (p.subpx) sp_ph = m0 / p.sp_rows;  // (scalar; sp_rows is a multiple of 256: a tile never straddles two phases)
+  }
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (size_t)sp_ph * p.N * p.K), 0,
+                                                                          (int)((size_t)p.N * p.K * 2), 0x00020000);
   unsigned xoff[PXM];
 #pragma unroll
   for (int q = 0; q < PXM; ++q) {
@@ -242,18 +248,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       if constexpr (YP) yoff[h][q] = G8_OOB;
       unsigned mk = live ? 1u : 0u;
       if (p.a_mode == MVOC_A_CONV3X3) {
-        const int img = (int)g8_udiv((unsigned)mm, p.mg_hwout, p.sh_hwout);
-        const int rem = mm - img * (p.hout * p.wout);
+        // (sub-pixel form: rows are phase-local source pixels, hout x wout = the source grid, taps 2 x 2 starting one pixel up /
+        // left for parity 0 and at the pixel for parity 1)
+        const bool sp = UPS && p.subpx;
+        const int ml = sp ? mm - sp_ph * p.sp_rows : mm;
+        const int ks = sp ? 2 : 3;
+        const int img = (int)g8_udiv((unsigned)ml, p.mg_hwout, p.sh_hwout);
+        const int rem = ml - img * (p.hout * p.wout);
         const int oy = (int)g8_udiv((unsigned)rem, p.mg_wout, p.sh_wout);
-        const int y0 = oy * p.stride - p.pad, x0 = (rem - oy * p.wout) * p.stride - p.pad;
+        const int y0 = oy * p.stride - p.pad + (sp ? sp_ph >> 1 : 0), x0 = (rem - oy * p.wout) * p.stride - p.pad + (sp ? sp_ph & 1 : 0);
         if constexpr (!AFF) rowoff[h][q] = (img * p.hsrc + y0) * p.wsrc + x0;
-        // tap (ky, kx) is inside the image iff row y0 + ky and column x0 + kx are: three column bits, replicated per live row
+        // tap (ky, kx) is inside the image iff row y0 + ky and column x0 + kx are: ks column bits, replicated per live row
         unsigned cb = 0;
         mk = 0;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) cb |= (unsigned)(x0 + t) < (unsigned)p.wup ? 1u << t : 0u;
+        for (int t = 0; t < 3; ++t) cb |= (t < ks && (unsigned)(x0 + t) < (unsigned)p.wup) ? 1u << t : 0u;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) mk |= (unsigned)(y0 + t) < (unsigned)p.hup ? cb << (3 * t) : 0u;
+        for (int t = 0; t < 3; ++t) mk |= (t < ks && (unsigned)(y0 + t) < (unsigned)p.hup) ? cb << (ks * t) : 0u;
         if (!live) mk = 0;
       } else if (p.a_mode == MVOC_A_TEMPORAL3) {
         const unsigned vf = g8_udiv((unsigned)mm, p.mg_hw, p.sh_hw);  // frame index over all videos
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   auto y_offset = [&](int h, int q) -> unsigned {
     const bool ok = (vmask[h] >> (16 * q + ytap)) & 1u;
     unsigned srow = (unsigned)((AFF ? rowoff[0][0] + h * 32 + q * 128 : rowoff[AFF ? 0 : h][AFF ? 0 : q]) + ytaprows);
-    if constexpr (UPS) {  // nearest-upsampled source: the row is not affine in the tap (three launches per forward)
+    if (UPS && !p.subpx) {  // nearest-upsampled source: the row is not affine in the tap (three launches per forward)
       const int ky = ytap / 3, kx = ytap - ky * 3;
       const int m = min(row_m(h, q), p.M - 1);
       const int hwout = p.hout * p.wout;
@@ -297,8 +308,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const bool second = ych0 >= p.c1;
     yld2 = (second ? p.lda2 : p.lda) * 2;
     ytaprows = 0;
-    if (p.a_mode == MVOC_A_CONV3X3) ytaprows = (ytap / 3) * p.wsrc + (ytap % 3);
-    else if (p.a_mode == MVOC_A_TEMPORAL3) ytaprows = (ytap - 1) * p.hw;
+    if (p.a_mode == MVOC_A_CONV3X3) {
+      if (UPS && p.subpx) ytaprows = (ytap >> 1) * p.wsrc + (ytap & 1);
+      else ytaprows = (ytap / 3) * p.wsrc + (ytap % 3);
+    } else if (p.a_mode == MVOC_A_TEMPORAL3) ytaprows = (ytap - 1) * p.hw;
     yso = (second ? ych0 - p.c1 : ych0) * 2;
     rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? p.a2 : p.a), 0, (int)G8_OOB, 0x00020000);
     if constexpr (YP) {
@@ -604,8 +617,20 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const int nbase = geglu ? nq_of(a) / 2 : nq_of(a);
     const int idx = ln + 64 * it;
     const int px = idx / nchunk, c = idx - px * nchunk;
-    const int m = m0 + wc * 64 + px, n = nbase + c * 8;
-    return (it < nchunk && n < p.n_store) ? (unsigned)(m * ld + n) * 2u : G8_OOB;
+    int m = m0 + wc * 64 + px;
+    const int n = nbase + c * 8;
+    bool ok = it < nchunk && n < p.n_store;
+    if constexpr (UPS) {
+      if (p.subpx) {  // source pixel (img, i, j) of phase (pa, pb) -> output pixel (2 i + pa, 2 j + pb) of the 2 x larger image
+        ok = ok && m < p.M;
+        const int ml = m - sp_ph * p.sp_rows;
+        const int img = (int)g8_udiv((unsigned)ml, p.mg_hwout, p.sh_hwout);
+        const int rem = ml - img * (p.hout * p.wout);
+        const int i_ = (int)g8_udiv((unsigned)rem, p.mg_wout, p.sh_wout);
+        m = (img * 2 * p.hout + 2 * i_ + (sp_ph >> 1)) * (2 * p.wout) + 2 * (rem - i_ * p.wout) + (sp_ph & 1);
+      }
+    }
+    return ok ? (unsigned)(m * ld + n) * 2u : G8_OOB;
   };
   auto load_resid = [&](int a, u32x4 (&rr)[XT * 2], int i0, int i1) {
 #pragma unroll

@@ -38,6 +38,11 @@ struct GemmArgs {
   float* stats;  // gemm8, optional: per 256-row tile and output channel {sum, sum of squares} of the stored values, fp32 [m_tiles][n_store][2]
   float* rowmom;  // gemm8, optional: per output row and n-tile {sum, sum of squares} of the stored values, fp32 [M][rowmom_ld][2]
   int rowmom_ld;
+  // gemm8, Upsample2D + conv in SUB-PIXEL form (mvoc_gemm_desc.upsample == 2): the 3 x 3 conv on a nearest-2x-upsampled image is, per
+  // output parity (a, b), a 2 x 2 conv on the SOURCE image with summed weights -- 4 taps instead of 9.  Rows [ph sp_rows, (ph + 1)
+  // sp_rows) are the source pixels (img, i, j) of phase ph = 2 a + b; their outputs go to pixel (2 i + a, 2 j + b); w holds the four
+  // phase kernels [4][N][4 cin]
+  int subpx, sp_rows;
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 

@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void gn_merge_parts(const float* __restrict__ 
   fin[i * 2 + 1] = rsqrtf(acc.m2 / acc.n + eps);
 }
 
+// NT: streaming (non-temporal) loads of the rows -- the rate of a copy on a tensor far larger than the caches (210 MB at the
+// finest level of a batch-5 step: 94 -> 76 us, tools/dbg/gn_bench.py), 10-15 % SLOWER on tensors the Infinity Cache still holds
+// from their producer: the host picks by size (mvoc_groupnorm_f16)
+template <bool NT>
 __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
   const int tid = threadIdx.x;
   const int cx = tid % p.aCW, ry = tid / p.aCW;
@@ -269,7 +273,10 @@ __global__ __launch_bounds__(256) void gn_apply(const GnArgs p) {
     for (; rr + 3 * p.aRY < r1; rr += 4 * p.aRY) {  // four loads in flight per thread
       half8_t v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.aRY, cc * 8));
+      for (int u = 0; u < 4; ++u) {
+        const half8_t* src = reinterpret_cast<const half8_t*>(gn_src(p, rowbase + rr + u * p.aRY, cc * 8));
+        v[u] = NT ? __builtin_nontemporal_load(src) : *src;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         half8_t o;
@@ -604,7 +611,7 @@ extern "C" int mvoc_groupnorm_apply_moments_f16(const mvoc_gn_desc* d, const voi
   const int ng = a.nsample * a.G;
   float* fin = a.ws + (long)a.nsample * a.nchunk * a.G * 3;
   hipLaunchKernelGGL(gn_merge_parts, dim3((ng + 255) / 256), dim3(256), 0, s, (const float*)parts, nparts, ng, a.eps, fin);
-  hipLaunchKernelGGL(gn_apply, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_apply<false>, dim3(a.nchunk, a.nsample), dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm_apply_moments");
 }
 
@@ -630,7 +637,9 @@ extern "C" int mvoc_groupnorm_f16(const mvoc_gn_desc* d, void* stream) {
     hipLaunchKernelGGL(gn_partial, grid, dim3(256), 0, s, a);
   }
   if (!a.inline_final) hipLaunchKernelGGL(gn_final, dim3(a.nsample, gn_final_blocks(a)), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(gn_apply, grid, dim3(256), 0, s, a);
+  static const long nt_min = getenv("MVOC_GN_NT_BYTES") ? atol(getenv("MVOC_GN_NT_BYTES")) : (160L << 20);
+  if ((long)d->nsample * d->rows_per_sample * d->c * 2 >= nt_min) hipLaunchKernelGGL(gn_apply<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gn_apply<false>, grid, dim3(256), 0, s, a);
   return mvoc_check_launch("groupnorm");
 }
 

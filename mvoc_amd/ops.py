@@ -162,10 +162,12 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
 
 
 def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
-            n_store=0, out=None, tile=0, split_k=0, pad_mode=0, sums=False):
+            n_store=0, out=None, tile=0, split_k=0, pad_mode=0, sums=False, w_subpixel=None):
     """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
     ``upsample_to=(H2, W2)`` folds a nearest upsample of the source into the gather (Upsample2D).
-    ``pad_mode=1``: zeros at the bottom / right only (``F.pad(x, (0,1,0,1))`` + ``conv2d(padding=0)``: VAE downsamplers)."""
+    ``pad_mode=1``: zeros at the bottom / right only (``F.pad(x, (0,1,0,1))`` + ``conv2d(padding=0)``: VAE downsamplers).
+    ``w_subpixel`` (``unet.pack_conv3x3_subpixel(w)``): with an exact 2x ``upsample_to`` the conv runs in its sub-pixel form -- four
+    2 x 2 parity kernels on the source image, 4 taps of matrix work instead of 9 (include/mvoc_hip.h: upsample == 2)."""
     _chk(x, "x"), _chk(w, "w"), _chk(bias, "bias"), _chk(x2, "x2"), _chk(resid, "resid"), _chk(rowadd, "rowadd")
     _rowmajor(x, "x")
     c1 = x.shape[1]
@@ -188,6 +190,15 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
     d.hup, d.wup = hup, wup
     d.split_k = split_k
     d.pad_mode = pad_mode
+    if (w_subpixel is not None and upsample_to is not None and (hup, wup) == (2 * h, 2 * wd) and stride == 1 and x2 is None and
+            resid is None and rowadd is None and pad_mode == 0 and (nimg * h * wd) % 256 == 0 and m >= 1024 and c1 % 64 == 0 and
+            tile in (0, 81) and out.stride(0) % 8 == 0 and cols % 8 == 0 and
+            (tile == 81 or (m // 256) * ((w.shape[0] + 255) // 256) * _CONCURRENCY.n >= 200)):  # (an under-filled grid keeps the split-K form)
+        _chk(w_subpixel, "w_subpixel")
+        if tuple(w_subpixel.shape) != (4 * w.shape[0], 4 * cin):
+            raise RuntimeError("conv3x3: w_subpixel must be pack_conv3x3_subpixel() of the same kernel")
+        d.upsample, d.w, d.k, d.split_k = 2, w_subpixel.data_ptr(), 4 * cin, 1
+        sums = False
     _gemm(d, x.device, out, sums)
     return out, ho, wo
 

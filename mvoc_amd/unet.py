@@ -56,6 +56,22 @@ def pack_conv3x3(w):
     return _pad_rows(_pad_cols(w.permute(0, 2, 3, 1).reshape(co, 9 * ci)))
 
 
+def pack_conv3x3_subpixel(w):
+    """[Cout, Cin, 3, 3] -> the four parity kernels of `nearest-2x upsample + conv3x3(pad 1)` as 2 x 2 convs on the source image
+    (include/mvoc_hip.h: upsample == 2): [4 * Cout_pad][2][2][Cin] -> [4 * Cout_pad, 4 * Cin], phase 2 a + b major.  Row parity a = 0:
+    the kernel rows (ky 0 | ky 1 + ky 2) fall on source rows (i - 1 | i); a = 1: (ky 0 + ky 1 | ky 2) on (i | i + 1); columns likewise.
+    Sums in fp32, rounded to fp16 once."""
+    w32 = w.float()
+    rows = {0: [(0,), (1, 2)], 1: [(0, 1), (2,)]}
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            k = torch.stack([torch.stack([sum(w32[:, :, ky, kx] for ky in rows[a][dy] for kx in rows[b][dx]) for dx in (0, 1)], -1)
+                             for dy in (0, 1)], -2)                       # [Cout, Cin, dy, dx]
+            out.append(_pad_rows(k.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(H16)))  # tap-major like pack_conv3x3
+    return torch.cat(out).contiguous()
+
+
 def pack_conv3x3_small(w):
     """[Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] for the direct small-channel conv"""
     return w.permute(0, 2, 3, 1).contiguous()
@@ -441,14 +457,22 @@ class TemporalConvLayer(Hookable):
 
 
 class Upsample2D:
+    """``F.interpolate(scale 2, nearest)`` + conv3x3 (diffusers Upsample2D; ``pnp_utils.py:919-934`` checks for it): the upsample is
+    never materialised -- folded into the conv's gather, and for the exact 2x case into the conv's WEIGHTS (sub-pixel form: per
+    output parity a 2 x 2 conv on the source image, 4 / 9 of the matrix work)"""
+    use_subpixel = os.environ.get("MVOC_SUBPIXEL", "1") != "0"  # MVOC_SUBPIXEL=0: A/B against the 9-tap gather
+
     def __init__(self, sd, prefix):
-        self.w = pack_conv3x3(sd[prefix + ".conv.weight"].to(H16))
+        w = sd[prefix + ".conv.weight"].to(H16)
+        self.w = pack_conv3x3(w)
+        self.w_sub = pack_conv3x3_subpixel(w) if w.shape[1] % 64 == 0 else None
         self.b = sd[prefix + ".conv.bias"].to(H16).contiguous()
 
     def forward(self, x, geo, size=None):
         B, F, H, W = geo
         up = size if size is not None else (2 * H, 2 * W)
-        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, upsample_to=tuple(up), n_store=self.b.shape[0], sums=True)
+        out, ho, wo = ops.conv3x3(x, self.w, self.b, nimg=B * F, h=H, wd=W, upsample_to=tuple(up), n_store=self.b.shape[0], sums=True,
+                                  w_subpixel=self.w_sub if Upsample2D.use_subpixel else None)
         return out, (B, F, ho, wo)
 
 

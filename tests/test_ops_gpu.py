@@ -230,6 +230,36 @@ def test_conv3x3_upsample(ops, size, tile):
     assert rel_l2(_from_rows(out, n, ho, wo), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(16, 64, 64, 8, 8), (4, 128, 320, 16, 16), (5, 64, 96, 16, 32)])
+def test_upsample_conv_subpixel_form(ops, n, cin, cout, h, w):
+    """Upsample2D + conv in sub-pixel form (mvoc_gemm_desc.upsample == 2: four 2 x 2 parity kernels on the source image instead of
+    the 9-tap gather on the upsampled one): exact on integer operands (the summed kernels stay fp16-exact), against
+    F.interpolate(nearest, 2x) + conv2d, and equal to the 9-tap form of the same call"""
+    from mvoc_amd.unet import pack_conv3x3, pack_conv3x3_subpixel
+    g = torch.Generator().manual_seed(n * 100 + cin + h)
+    x = _ints(g, (n, cin, h, w), -2, 2)
+    wt = _ints(g, (cout, cin, 3, 3))
+    wt[torch.rand(wt.shape, generator=g) < 0.4] = 0
+    b = _ints(g, (cout,), -4, 4)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    assert ref.abs().max() < 2048
+    xs, wd, bd = dev(_nhwc(x)), dev(wt), dev(b)
+    sub, ho, wo = ops.conv3x3(xs, pack_conv3x3(wd), bd, nimg=n, h=h, wd=w, upsample_to=(2 * h, 2 * w), n_store=cout, tile=81,
+                              w_subpixel=pack_conv3x3_subpixel(wd))
+    nine, _, _ = ops.conv3x3(xs, pack_conv3x3(wd), bd, nimg=n, h=h, wd=w, upsample_to=(2 * h, 2 * w), n_store=cout, tile=81)
+    assert (ho, wo) == (2 * h, 2 * w)
+    assert torch.equal(_from_rows(nine, n, ho, wo).float().cpu(), ref)
+    bad = (_from_rows(sub, n, ho, wo).float().cpu() != ref)
+    assert not bad.any(), f"{int(bad.sum())} wrong outputs, first at {bad.nonzero()[0].tolist()}"
+    # random operands: the parity kernels are fp16 roundings of fp32 sums -- one more rounding than the 9-tap form
+    xr = torch.randn(n, cin, h, w, generator=g).half()
+    wr = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).half()
+    refr = F.conv2d(F.interpolate(xr.float(), scale_factor=2.0, mode="nearest"), wr.float(), b, padding=1)
+    subr, _, _ = ops.conv3x3(dev(_nhwc(xr)), pack_conv3x3(dev(wr)), bd, nimg=n, h=h, wd=w, upsample_to=(2 * h, 2 * w), n_store=cout,
+                             tile=81, w_subpixel=pack_conv3x3_subpixel(dev(wr)))
+    assert rel_l2(_from_rows(subr, n, ho, wo), refr) < 1.5e-3
+
+
 @pytest.mark.parametrize("tile", [0, 11, 13, 61, 81, 82])
 @pytest.mark.parametrize("frames", [1, 3, 16])
 def test_tconv3(ops, frames, tile):

@@ -23,7 +23,17 @@ for f in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if kern in r["Kernel_Name"]:
             agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for name, c in agg.items():
+grand = collections.defaultdict(float)
+lib = [n for n in agg if not any(t in n for t in ("at::native", "rocclr", "rocblas", "delay_kernel"))]  # libmvoc_hip's own kernels
+for name in lib:
+    for k, v in agg[name].items():
+        grand[k] += sum(v)
+if len(lib) > 1 and grand.get("GRBM_GUI_ACTIVE"):
+    cyc = grand["GRBM_GUI_ACTIVE"] / 8
+    print(f"== ALL {len(lib)} matching library kernels together (weighted by their cycles; torch's own fill / copy / init kernels left out): MFMA utilisation "
+          f"{100 * grand['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * 256 * cyc):.1f} % | waves waiting "
+          f"{100 * grand.get('SQ_WAIT_ANY', 0) / max(grand.get('SQ_WAVE_CYCLES', 0), 1):.1f} %")
+for name, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
     n = len(c.get("GRBM_GUI_ACTIVE", []))
     print(f"== {name}  ({n} dispatches)")
     tot = {k: sum(v) for k, v in c.items()}
