@@ -362,6 +362,7 @@ def roofline_leg(job, steps):
         "flops_per_launch_avg": g["work"] / max(g["launches"], 1),
         "share_of_gpu_time": round(g["ms"] / total_ms, 4) if total_ms else None,
         "algorithmic_tflop_all_steps": round(alg / 1e12, 2),
+        "executed_matrix_tflop_all_steps": round(sum(fam[k]["work"] for k in ("gemm", "flash_attn", "temporal_fused") if k in fam) / 1e12, 2),
         "by_family_ms": {k: round(v["ms"], 3) for k, v in fam.items()},
         "by_family_launches": {k: int(v["launches"]) for k, v in fam.items()},
         "flash_attn_tflops": round(_rate(fam, "flash_attn", 1e9), 2),
@@ -748,6 +749,17 @@ def main():
                 "timed_composition_steps": {"qk_injection_only": sum(1 for j in range(sum(1 for k in range(args.steps) if job.is_comp(k))) if j % 10 != 9),
                                             "feature_injection": sum(1 for j in range(sum(1 for k in range(args.steps) if job.is_comp(k))) if j % 10 == 9)},
                 "job_average_ms_per_step": round((150 * (inv_conc_ms if inv_conc_ms is not None else inv_ms) + 45 * comp_ms + 5 * compf_ms) / 200, 3),
+                "work_not_executed": "every step delivers the reference loop's result; what the engine does not run, because nothing reads it "
+                                     "or it is computed twice (each switchable, each with a parity test): (1) composition, conv_out-"
+                                     "injection steps (5 of 50): the two destination chunks (unet.prune_dead_chunks, round 2); (2) "
+                                     "composition, Q/K-only steps: the three source chunks behind the last injection site "
+                                     "(pipeline.prune_source_tail: rest of the last temporal transformer, conv_norm_out, conv_out); (3) "
+                                     "composition: the unconditional chunk up to the first cross-attention -- identical to the "
+                                     "conditional chunk there (pipeline.share_cfg_prefix); (4) both step kinds: 5 of the 9 taps of the "
+                                     "three Upsample2D convs (sub-pixel form: four 2 x 2 parity kernels with summed weights). "
+                                     "tflop_per_*_step / end_to_end_tflops below are the REFERENCE forward's FLOP model (SURVEY 8d), "
+                                     "i.e. work delivered per second, not matrix work executed: roofline.achieved counts the 2 m n k of the "
+                                     "launches that ran",
                 "tflop_per_inversion_step": round(f1 / 1e12, 2), "tflop_per_composition_step": round(f5 / 1e12, 2),
                 "end_to_end_tflops": round(sum(f1 if not job.is_comp(k) else (f3 if (sum(1 for q in range(k) if job.is_comp(q)) % 10 == 9) else f5)
                                                for k in range(args.steps)) / dt / 1e12, 2),

@@ -181,7 +181,7 @@ class Linear:
 
     USE_GN_FOLD = os.environ.get("MVOC_GN_FOLD", "1") != "0"  # MVOC_GN_FOLD=0: A/B against GroupNorm + linear
 
-    def call_gn(self, eng, x, norm, *, nsample, rows_per_sample, groups, eps, rowmom=False):
+    def call_gn(self, eng, x, norm, *, nsample, rows_per_sample, groups, eps, rowmom=False, video_norm=False):
         """GroupNorm(x) -> this linear (no activation in between: GN -> proj_in, pnp_utils.py:185-191, 433-438).  Where the
         activation-stationary kernel takes the call (K = 320 and many rows: the finest level) the norm is FOLDED into
         per-sample weights (ops.groupnorm_fold_xs) and the linear reads the raw rows: the normalised tensor -- a read and a
@@ -190,10 +190,10 @@ class Linear:
                 and x.shape[0] == nsample * rows_per_sample and nsample <= 4096):
             wp = ops.groupnorm_fold_xs(x, *norm, self.w, self.b, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps)
             return ops.xs_linear(x, wp, self.w.shape[0], n_store=self.n, set_rows=rows_per_sample)
-        if eng.shard is None:
-            h = ops.groupnorm(x, *norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=False)
-        else:
+        if video_norm:  # statistics over the frames too: a frame-sharded clip merges the ranks' moments (eng.groupnorm5d)
             h = eng.groupnorm5d(x, norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=False)
+        else:
+            h = ops.groupnorm(x, *norm, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps, silu=False)
         return self(h, rowmom=rowmom)
 
     def fold_layernorm(self, gamma, beta, eps=1e-5):
@@ -353,7 +353,8 @@ class TransformerTemporalModel(_TransformerBase):
         B, F, H, W = geo
         hw = H * W
         blk = self.transformer_blocks[0]
-        h = self.proj_in.call_gn(eng, x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, rowmom=True)
+        h = self.proj_in.call_gn(eng, x, self.norm, nsample=B, rows_per_sample=F * hw, groups=self.groups, eps=1e-6, rowmom=True,
+                                 video_norm=True)
         c = blk.dim
         for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
             proc = attn.processor

@@ -58,6 +58,8 @@ def unet(out_dir, which):
         attention_head_dim=64, transformer_in_heads=2, context_pool=8)
     eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
     eng.prune_dead_chunks = False  # (frame-sharded forwards compute every chunk: compare like with like)
+    from mvoc_amd.unet import Linear
+    Linear.USE_GN_FOLD = False  # (... and apply their GroupNorms as kernels -- the fold into proj_in is a single-GPU form)
     report = {"rank": rank}
 
     def inputs(B, F, h, w, seed):
@@ -182,6 +184,8 @@ def rccl_native(out_dir):
                      attention_head_dim=64, transformer_in_heads=2, context_pool=8)
     eng = I2VGenXLUNet(cfg, device=dev).init_random(31)
     eng.prune_dead_chunks = False  # (frame-sharded forwards compute every chunk: compare like with like)
+    from mvoc_amd.unet import Linear
+    Linear.USE_GN_FOLD = False  # (... and apply their GroupNorms as kernels -- the fold into proj_in is a single-GPU form)
     r = lambda *s_: torch.randn(*s_, generator=g).half().to(dev)
     inp = (r(1, 4, 4, 16, 16), torch.tensor([500.0]).to(dev), torch.full((1,), 8.0).to(dev), r(1, 4, 4, 16, 16), r(1, 4, 4, 16, 16),
            r(1, 4, 64), r(1, 7, 64))

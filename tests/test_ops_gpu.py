@@ -958,7 +958,7 @@ def test_gemm_row_moments_and_layernorm_statistics_from_them(ops, m, n, k, resid
     rm = getattr(out, "row_moments", None)
     assert rm is not None
     mom, tw = rm
-    assert tw == (256 if tile == 81 or act else 320) and tuple(mom.shape) == (m, (n + 127) // 128, 2)
+    assert tw == (256 if tile == 81 or act else 320) and tuple(mom.shape) == (m, (n + 255) // 256, 2)
     o = out.float()
     for t in range((n + tw - 1) // tw):
         sl = o[:, t * tw:min(n, (t + 1) * tw)]
