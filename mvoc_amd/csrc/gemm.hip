@@ -979,7 +979,9 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                      // the epilogue's vector table (gemm8.hip): 16-byte loads of bias / LayerNorm vectors / row-add rows, at most
                      // 5 row-add rows per 256-row tile
                      ((uintptr_t)d->bias & 15) == 0 && ((uintptr_t)d->ln_rowsum & 15) == 0 && ((uintptr_t)d->ln_bias & 15) == 0 &&
-                     (!d->rowadd || (((uintptr_t)d->rowadd & 15) == 0 && d->ld_rowadd % 8 == 0 && a.rowadd_div >= 64));
+                     (!d->rowadd || (((uintptr_t)d->rowadd & 15) == 0 && d->ld_rowadd % 8 == 0 && a.rowadd_div >= 64)) &&
+                     // the folded-upsample instantiation carries the plain epilogue only (gemm8.hip: launch8)
+                     (!d->upsample || (d->act == MVOC_ACT_NONE && !d->ln_rowsum));
   if (a.subpx) {
     MVOC_REQUIRE(g8_ok, -2, "gemm: the sub-pixel upsample conv runs on the eight-phase tiles only (k, cin %% 64 == 0, 16-byte addressable output)");
     tile = 81;

@@ -827,11 +827,18 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm8: grid of %ld blocks", nblk);
     return -2;
   }
-  if (epi == 1) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 1>), dim3((unsigned)nblk), dim3(512), 0, s, a);
-  else if (epi == 2) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 2>), dim3((unsigned)nblk), dim3(512), 0, s, a);
-  else if (epi == 3) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 3>), dim3((unsigned)nblk), dim3(512), 0, s, a);
-  else if constexpr (XT == 4) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 0>), dim3((unsigned)nblk), dim3(512), 0, s, a);
-  else return -9;  // (unreachable: mvoc_launch_gemm8 sends the general epilogue of a 320-wide request to the 256-wide tile)
+  if constexpr (UPS) {
+    // the folded-upsample form exists with the plain epilogue only (Upsample2D's conv: bias): its other epilogue forms spilled
+    // registers once the sub-pixel gather joined it, and no caller has them (gemm.hip sends such a request to the general tiles)
+    if (epi != 1) return -9;
+    hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 1>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  } else {
+    if (epi == 1) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 1>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else if (epi == 2) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 2>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else if (epi == 3) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 3>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else if constexpr (XT == 4) hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 0>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    else return -9;  // (unreachable: mvoc_launch_gemm8 sends the general epilogue of a 320-wide request to the 256-wide tile)
+  }
   return mvoc_check_launch("gemm8_kernel");
 }
 
