@@ -21,7 +21,7 @@ out, kern = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in kern.split("|")):  # <kernel-name substring>: alternatives separated by |
             agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 grand = collections.defaultdict(float)
 lib = [n for n in agg if not any(t in n for t in ("at::native", "rocclr", "rocblas", "delay_kernel"))]  # libmvoc_hip's own kernels
