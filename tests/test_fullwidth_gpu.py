@@ -198,7 +198,6 @@ def test_ext_forward_with_all_hooks_full_width(pair, trio):
     # (the prefix then runs at another row count, i.e. on other tiles: two fp16 evaluations of the network, each within tolerance
     # of the oracle, differ from each other by about as much)
     assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD and relp <= REL_L2_FWD, (rel, mx, relp)
-    assert torch.equal(plain[3, :, :, :2], plain[3, :, :, :2])
 
 
 def test_one_inversion_and_one_composition_step_full_width(pair, trio):
