@@ -256,6 +256,32 @@ def test_one_inversion_and_one_composition_step_full_width(pair, trio):
         rel, _ = _metrics(cst["latents"], ref)
         print(f"full-width composition step t=981: latents rel-L2 {rel:.2e}")
         assert rel <= REL_L2_STEP, rel  # (measured 1.5e-4: at t = 981 the update is dominated by the latent itself)
+        # ---- a Q/K-only step (t = 861) as the job runs it: the unconditional and the conditional chunk carry the same image latents
+        # (the reference builds both from the main image), so the loop shares their prefix AND prunes the source chunks' tail --
+        # against the oracle's five-chunk forward + CFG + DDIM; and against the same step with both reductions off
+        z = {k: v.clone() for k, v in y.items()}
+        for k in ("il1", "il"):
+            z[k][3] = z[k][4]
+        zcond = dict(encoder_hidden_states=z["eh"].half().cuda(), image_embeddings=z["ie"].half().cuda(),
+                     image_latents_first=z["il1"].half().cuda(), image_latents=z["il"].half().cuda(),
+                     fps=torch.full((5,), 8.0, device="cuda"))
+        outs = {}
+        for on in (True, False):
+            pipe.prune_source_tail = pipe.share_cfg_prefix = on
+            zst = pipe.make_composition_state(lat.cuda(), zcond, masks, 9.0)
+            assert zst["share_cfg_prefix"] == on
+            pipe.composition_step(zst, 861, src[0].cuda(), [src[1].cuda(), src[2].cuda()], ctable[cindex[861]], None)
+            outs[on] = zst["latents"].clone()
+        pipe.prune_source_tail = pipe.share_cfg_prefix = True
+        pst.t, pst.masks = 861, masks
+        rn = o.forward_ext(inp, 861, z["fps"], z["il1"], z["il"], z["ie"], z["eh"])[0].half()
+        ref = loops_ref.scheduler_step_5d(rs, loops_ref.cfg_combine(rn[3:4], rn[4:5], 9.0), 861, lat)
+        rel, _ = _metrics(outs[True], ref)
+        relo, _ = _metrics(outs[False], ref)
+        relb, _ = _metrics(outs[True], outs[False])
+        print(f"full-width composition step t=861 (shared CFG prefix + pruned source tail): latents rel-L2 {rel:.2e} vs oracle "
+              f"({relo:.2e} with both off; {relb:.2e} between the two)")
+        assert rel <= REL_L2_STEP and relo <= REL_L2_STEP, (rel, relo)
 
 
 def _ulp_distance(a, b):
