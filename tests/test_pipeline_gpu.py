@@ -514,6 +514,24 @@ def test_bench_two_rank_protocol(tmp_path):
     assert abs(j["value"] - 2 * 4 / (j["ms_per_step"] * 4 / 1e3)) / j["value"] < 1e-3  # aggregate = world * steps / time
 
 
+def test_bench_gpus2_launched_plainly_on_the_gpu(tmp_path):
+    """the driver's own command form -- `python bench.py --gpus 2 ...`, no torchrun around it -- with the real workload: bench.py
+    starts its two ranks as child processes before touching the GPU and relays rank 0's line (this one-GPU box: both ranks on the
+    device, MVOC_BENCH_OVERSUBSCRIBE=1, gloo standing in for RCCL)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MVOC_BENCH_BACKEND="gloo", MVOC_BENCH_OVERSUBSCRIBE="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "4", "--latent", "32",
+           "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "2 independent shards" in j["config"]["parallelism"]
+    assert "3 concurrent source clip(s) per rank" in j["config"]["parallelism"]
+
+
 def test_fifty_step_inversion_drift_vs_oracle():
     """SURVEY 8d tolerance proposal: latents after a full 50-step schedule within rel-L2 2e-2 of the fp32 oracle loop
     (per-step UNet noise of ~2e-3 accumulated through the inverse-DDIM recurrence), toy UNet, cfg 1.0"""
