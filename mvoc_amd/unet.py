@@ -162,6 +162,11 @@ class Linear:
         """the activation-stationary kernel takes this call: K in registers (64 / 128 / 320), single contiguous source, plain
         epilogue (bias | folded LayerNorm constant, activation, residual), many rows"""
         k = self.w.shape[1]
+        if (Linear.resid_tiled_rows and kw.get("resid") is not None and x.shape[0] >= Linear.resid_tiled_rows and self.w.shape[0] <= 320):
+            # to_out / proj_out + residual at batch 5: since the 320-wide eight-phase tile stores plain and prefetches its residual
+            # (round 4) it is 10 % faster than the activation-stationary kernel on this HBM-bound launch (tools/xs_bench.py, round 5:
+            # 161-167 us against 182-183 at 327 680 rows; equal at 65 536)
+            return False
         return (Linear.use_xs and k in ops.XS_K and x.shape[0] >= self.XS_MIN_ROWS and
                 x.dim() == 2 and x.shape[1] == k and x.is_contiguous() and
                 not (set(kw) - {"act", "resid", "out"}) and (kw.get("resid") is None or kw.get("act", ACT_NONE) != ACT_GEGLU) and
@@ -169,6 +174,7 @@ class Linear:
                 (kw.get("out") is None or kw["out"].stride(0) % 8 == 0) and (kw.get("resid") is None or kw["resid"].stride(0) % 8 == 0))
 
     use_xs = os.environ.get("MVOC_XS", "1") != "0"  # MVOC_XS=0: A/B against the tiled GEMM (diagnostics)
+    resid_tiled_rows = int(os.environ.get("MVOC_XS_RESID_TILED_ROWS", "131072"))  # 0: the residual projections stay on xslin (A/B)
 
     def __call__(self, x, sums=False, rowmom=False, **kw):
         """``sums`` / ``rowmom``: ask the GEMM for the GroupNorm / LayerNorm statistics of its output (ops._gemm; the

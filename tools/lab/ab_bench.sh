@@ -14,5 +14,6 @@ for rep in 1 2; do
   run no-share MVOC_SHARE_CFG_PREFIX=0
   run no-fold  MVOC_GN_FOLD=0
   run no-subpx MVOC_SUBPIXEL=0
+  run xs-resid MVOC_XS_RESID_TILED_ROWS=0
   run all-off  MVOC_PRUNE_SOURCE_TAIL=0 MVOC_SHARE_CFG_PREFIX=0 MVOC_GN_FOLD=0 MVOC_SUBPIXEL=0 MVOC_GN_NT_BYTES=99999999999
 done
