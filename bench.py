@@ -538,28 +538,56 @@ def longclip(args, rank, world, device, dist):
         dist.destroy_process_group()
 
 
+def visible_gpus_without_hip():
+    """GPUs this process may use, counted WITHOUT a HIP / HSA call (torch.cuda.device_count() can fall through to hipGetDeviceCount,
+    which initialises the runtime in a parent that is about to start child ranks): KFD topology nodes that have SIMDs, cut down by
+    the *_VISIBLE_DEVICES lists the runtime would apply"""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` (N > 1) without torchrun around it: start the N ranks as CHILD processes -- this parent has
-    made no HIP call (counting devices does not initialise the GPU) and never replaces itself -- relay what rank 0 prints and
-    return the launcher's exit status (non-zero as soon as one rank fails: torch.distributed.run tears the others down)."""
-    import socket
+    """`python bench.py --gpus N` (N > 1) without torchrun around it: start the N ranks as CHILD processes -- this parent makes no
+    HIP call (devices are counted through sysfs) and never replaces itself -- relay what rank 0 prints and return the launcher's
+    exit status (non-zero as soon as one rank fails: torch.distributed.run tears the others down).  The launcher picks its own
+    rendezvous port (--standalone), on 127.0.0.1."""
     import subprocess
     n = args.gpus
     if not args.selftest_launch:
-        visible = torch.cuda.device_count()
+        visible = visible_gpus_without_hip()
         if n > visible and os.environ.get("MVOC_BENCH_OVERSUBSCRIBE") != "1":  # (the one-GPU test box runs two ranks on its GPU)
             raise SystemExit(f"bench.py: --gpus {n} but only {visible} device(s) visible")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     for line in proc.stdout:  # rank 0's JSON line (other ranks print nothing on stdout); stderr passes through
         sys.stdout.write(line)
         sys.stdout.flush()
     return proc.wait()
+
+
+def rank_identity(rank, local_rank, device):
+    """what lets a reader of the N-GPU line confirm that N ranks ran on N distinct GPUs: device index, name, uuid / PCI address"""
+    pr = torch.cuda.get_device_properties(device)
+    uuid = getattr(pr, "uuid", None)
+    pci = None
+    if hasattr(pr, "pci_bus_id"):
+        pci = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    return {"rank": rank, "local_rank": local_rank, "device_index": device.index, "device_name": pr.name, "cus": pr.multi_processor_count,
+            "uuid": None if uuid is None else str(uuid), "pci": pci, "pid": os.getpid()}
 
 
 def selftest_launch(args, rank, world):
@@ -611,6 +639,16 @@ def main():
             dist.init_process_group("nccl", device_id=device)  # the metric workload uses it for barrier + max-reduce only
         else:
             dist.init_process_group(backend)
+    # N ranks on N distinct GPUs: gathered BEFORE anything is timed (a launcher that put two ranks on one device would report a
+    # scaling figure of something else); MVOC_BENCH_OVERSUBSCRIBE=1 is the one-GPU test box
+    ident = rank_identity(rank, local_rank, device)
+    idents = [ident]
+    if dist is not None:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        keys = {(i["uuid"] or i["pci"] or f"index-{i['device_index']}") for i in idents}
+        if len(keys) != world and os.environ.get("MVOC_BENCH_OVERSUBSCRIBE") != "1":
+            raise SystemExit(f"bench.py: {world} ranks on {len(keys)} distinct device(s): {idents}")
 
     if args.workload == "longclip":
         return longclip(args, rank, world, device, dist)
@@ -668,13 +706,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
+        own[0] = dt_
         if dist is not None:
             tt = torch.tensor([dt_], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
         return dt_
 
+    own = [0.0]
     dt = timed_region()
+    ident["ms_per_step"] = round(own[0] / args.steps * 1e3, 3)  # this rank's own clock around the same K steps (the line's is the MAX)
+    idents = [ident]
+    if dist is not None:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
     dt_seq = None
     if concurrent:  # the same K steps in the rounds 1-3 form (one inversion step after the other), reported beside the metric
         job.concurrent = False
@@ -736,6 +781,9 @@ def main():
                 "parallelism": (f"{world} independent shards, one per GPU, no data-path collective; every rank runs the whole job mix, i.e. "
                                 f"{3 if was_concurrent else 1} concurrent source clip(s) per rank" if world > 1 else
                                 f"single GPU, {3 if was_concurrent else 1} concurrent source clip(s)"),
+                "ranks": idents,
+                "collective_backend": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                                 "used_for": "barrier + max-over-ranks of the timed region + this table only"},
                 "hip_graphs": not args.no_graphs,
                 "loop_invariant_conditioning": "context tokens, cross-attention K/V of them and the image-latent stem are computed once "
                                                "per loop (I2VGenXLUNet.prepare_conditioning), bit-identical to recomputing them per step",
@@ -761,6 +809,7 @@ def main():
                                      "i.e. work delivered per second, not matrix work executed: roofline.achieved counts the 2 m n k of the "
                                      "launches that ran",
                 "tflop_per_inversion_step": round(f1 / 1e12, 2), "tflop_per_composition_step": round(f5 / 1e12, 2),
+                "executed_tflops": None,  # filled from the roofline leg: the matrix work that RAN per second of the timed region
                 "end_to_end_tflops": round(sum(f1 if not job.is_comp(k) else (f3 if (sum(1 for q in range(k) if job.is_comp(q)) % 10 == 9) else f5)
                                                for k in range(args.steps)) / dt / 1e12, 2),
             },
@@ -770,6 +819,8 @@ def main():
         try:
             job.concurrent = False  # (per-launch HIP-event brackets: one stream, one launch at a time)
             out["roofline"] = roofline_leg(job, args.steps)
+            # (the eager repeat executes the launches of the timed steps: its matrix work over the TIMED region's clock)
+            out["config"]["executed_tflops"] = round(out["roofline"]["executed_matrix_tflop_all_steps"] / dt, 2)
         except Exception as e:  # noqa: BLE001
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

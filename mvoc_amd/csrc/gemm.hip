@@ -1106,7 +1106,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
         a.stats = (float*)d->chan_sums;
         g_sums_written = 1;
       }
-      if (d->row_moments && a.split_k == 1 && d->act != MVOC_ACT_GEGLU && a.n_store == a.N) {  // LayerNorm statistics likewise
+      if (d->row_moments && a.split_k == 1 && d->act != MVOC_ACT_GEGLU && a.n_store == a.N && !a.subpx) {  // (sub-pixel form: tile rows are not output rows)  // LayerNorm statistics likewise
         MVOC_REQUIRE(d->row_moments_ld >= (a.N + 255) / 256, -2, "gemm: row_moments_ld %d < ceil(n / 256)", d->row_moments_ld);
         a.rowmom = (float*)d->row_moments;
         a.rowmom_ld = d->row_moments_ld;

@@ -337,8 +337,11 @@ __global__ __launch_bounds__(256) void gn_fold_xs_kernel(const GnArgs p, const h
     const half8_t bv = *reinterpret_cast<const half8_t*>(p.beta + col);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      // the mean term from the weight AS ROUNDED above (the consumer computes sum fl16(W') x + c'): then y = sum W' (x - mean) + W beta
+      // + b and the rounding error of W' scales with |x - mean|, not with |mean| (a group whose mean is many sigma off zero)
       const float* f = fin + 2 * ((col + e) / p.cpg);
-      acc += (float)wv[e] * ((float)bv[e] - (float)gv[e] * f[0] * f[1]);
+      const float wr = (float)(half_t)((float)wv[e] * ((float)gv[e] * f[1]));
+      acc += (float)wv[e] * (float)bv[e] - wr * f[0];
     }
   }
   acc += __shfl_xor(acc, 1);

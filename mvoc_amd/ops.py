@@ -161,6 +161,10 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
     return out
 
 
+SUBPIXEL_MIN_TILES = 200  # the sub-pixel form of Upsample2D + conv needs a grid that fills the chip; under it the 9-tap split-K form
+#                           stays (8 -> 16 at batch 1).  Tests set 0 to put every upsampler of a small forward on the sub-pixel form.
+
+
 def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, rowadd=None, rowadd_div=1, resid=None,
             n_store=0, out=None, tile=0, split_k=0, pad_mode=0, sums=False, w_subpixel=None):
     """3x3 conv, pad 1, on channels-last images x [nimg*h*wd, C1] (+ x2 [.., C2]); w [N, Kpad>=9*(C1+C2)] tap-major.
@@ -190,10 +194,14 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
     d.hup, d.wup = hup, wup
     d.split_k = split_k
     d.pad_mode = pad_mode
+    lim = 1 << 31  # the eight-phase tiles address every operand through 32-bit MUBUF offsets (gemm.hip: g8_ok -- mirrored here,
+    #               because a sub-pixel request the library cannot place on them is an error there, not a fall-back)
     if (w_subpixel is not None and upsample_to is not None and (hup, wup) == (2 * h, 2 * wd) and stride == 1 and x2 is None and
             resid is None and rowadd is None and pad_mode == 0 and (nimg * h * wd) % 256 == 0 and m >= 1024 and c1 % 64 == 0 and
             tile in (0, 81) and out.stride(0) % 8 == 0 and cols % 8 == 0 and
-            (tile == 81 or (m // 256) * ((w.shape[0] + 255) // 256) * _CONCURRENCY.n >= 200)):  # (an under-filled grid keeps the split-K form)
+            w_subpixel.is_contiguous() and out.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0) and
+            nimg * h * wd * x.stride(0) * 2 < lim and m * out.stride(0) * 2 < lim and w.shape[0] * 4 * cin * 2 < lim and
+            (tile == 81 or (m // 256) * ((w.shape[0] + 255) // 256) * _CONCURRENCY.n >= SUBPIXEL_MIN_TILES)):  # (an under-filled grid keeps the split-K form)
         _chk(w_subpixel, "w_subpixel")
         if tuple(w_subpixel.shape) != (4 * w.shape[0], 4 * cin):
             raise RuntimeError("conv3x3: w_subpixel must be pack_conv3x3_subpixel() of the same kernel")

@@ -154,14 +154,23 @@ class I2VGenXLPipeline:
     # ---- reference plumbing ------------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, path, torch_dtype=H16, variant="fp16", device="cuda:0", **kw):
-        """Loads ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` (diffusers layout).  The text / image
-        encoders and the VAE of the checkpoint are outside this path's scope (see module docstring)."""
+        """``I2VGenXLPipeline.from_pretrained(PRETRAINED_MODEL_PATH, torch_dtype=fp16, variant="fp16")`` of the reference drivers
+        (``inverse.py:113-118``, ``composite.py:76-85``): the UNet from ``<path>/unet/config.json`` (the I2VGen-XL default when the file
+        is absent) + ``<path>/unet/diffusion_pytorch_model[.fp16].safetensors`` (diffusers layout).  The checkpoint's VAE and CLIP
+        towers are attached by the drivers (``mvoc_amd.vae.attach_vae`` / ``mvoc_amd.clip.attach_clip``)."""
+        import json
         from safetensors.torch import load_file
         from .unet import I2VGenXLUNet
+        from .unet_spec import UNetConfig
+        cfg = None
+        cf = os.path.join(path, "unet", "config.json")
+        if os.path.exists(cf):
+            with open(cf) as fh:
+                cfg = UNetConfig.from_diffusers(json.load(fh))
         for name in (f"diffusion_pytorch_model.{variant}.safetensors", "diffusion_pytorch_model.safetensors"):
             f = os.path.join(path, "unet", name)
             if os.path.exists(f):
-                unet = I2VGenXLUNet(device=device).load_state_dict(load_file(f))
+                unet = I2VGenXLUNet(cfg, device=device).load_state_dict(load_file(f))
                 return cls(unet, **kw)
         raise FileNotFoundError(f"no UNet weights under {path}/unet (expected diffusers safetensors); for synthetic "
                                 "weights use mvoc_amd.pipeline.I2VGenXLPipeline.synthetic()")
@@ -455,7 +464,11 @@ class I2VGenXLPipeline:
     # ---- composition --------------------------------------------------------------------------------------
     def make_composition_state(self, latents, cond, masks, guidance_scale):
         """static buffers + the captured iteration variants of the composition loop.
-        cond: dict(encoder_hidden_states [n,77,D], image_embeddings [n,F,D], image_latents_first, image_latents, fps)"""
+        cond: dict(encoder_hidden_states [n,77,D], image_embeddings [n,F,D], image_latents_first, image_latents, fps).
+        The state keeps its OWN copy of ``cond``: the hoisted conditioning (``prepare_conditioning``) and the shared-CFG-prefix
+        decision below are taken once from these values, so a caller that later rewrites its tensors in place cannot make the
+        captured iterations disagree with them -- new conditioning = a new state."""
+        cond = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in cond.items()}
         n_obj = len(masks)
         do_cfg = guidance_scale > 1  # off: batch [bg, objs.., cond], one destination chunk for the injections (SURVEY 8f-4)
         nb = n_obj + (3 if do_cfg else 2)

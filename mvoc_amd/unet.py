@@ -191,7 +191,9 @@ class Linear:
         """GroupNorm(x) -> this linear (no activation in between: GN -> proj_in, pnp_utils.py:185-191, 433-438).  Where the
         activation-stationary kernel takes the call (K = 320 and many rows: the finest level) the norm is FOLDED into
         per-sample weights (ops.groupnorm_fold_xs) and the linear reads the raw rows: the normalised tensor -- a read and a
-        write of the whole activation -- never exists.  Elsewhere: the GroupNorm kernels, then the linear."""
+        write of the whole activation -- never exists.  Elsewhere: the GroupNorm kernels, then the linear.
+        ``rowmom`` (row moments of the output for the LayerNorm behind it) is honoured on the unfolded path only: the
+        activation-stationary kernel emits none, and its consumers take their row statistics from ``row_stats`` then."""
         if (Linear.USE_GN_FOLD and eng.shard is None and self._xs_ok(x, {}) and rows_per_sample % 256 == 0 and self.w.shape[0] == self.n
                 and x.shape[0] == nsample * rows_per_sample and nsample <= 4096):
             wp = ops.groupnorm_fold_xs(x, *norm, self.w, self.b, nsample=nsample, rows_per_sample=rows_per_sample, groups=groups, eps=eps)

@@ -39,6 +39,26 @@ class UNetConfig:
             return cls(**cfg)
         return cls(**{k: getattr(cfg, k) for k in cls().__dict__})
 
+    @classmethod
+    def from_diffusers(cls, d):
+        """``<checkpoint>/unet/config.json`` as diffusers 0.27.2 writes it (``I2VGenXLUNet.register_to_config``: sample_size,
+        in / out_channels, down / up_block_types, block_out_channels, layers_per_block, norm_num_groups, cross_attention_dim,
+        attention_head_dim, num_attention_heads + ``_class_name`` / ``_diffusers_version``) -> UNetConfig.  Keys this engine has no
+        use for are dropped; ``attention_head_dim`` may be a list (one entry per block, all equal in I2VGen-XL);
+        ``transformer_in_heads`` / ``context_pool`` are constants of the architecture in diffusers (8 heads, 32 x 32 context pool) and
+        only read when a (toy) checkpoint states them."""
+        known = cls().__dict__
+        kw = {k: d[k] for k in known if k in d and d[k] is not None}
+        hd = kw.get("attention_head_dim")
+        if isinstance(hd, (list, tuple)):
+            if len(set(hd)) != 1:
+                raise ValueError(f"unet/config.json: attention_head_dim {hd} differs between blocks: not I2VGen-XL")
+            kw["attention_head_dim"] = int(hd[0])
+        name = d.get("_class_name")
+        if name not in (None, "I2VGenXLUNet"):
+            raise ValueError(f"unet/config.json describes a {name}, not an I2VGenXLUNet")
+        return cls(**kw)
+
 
 def _lin(sd, name, cin, cout, bias=True):
     sd[name + ".weight"] = (cout, cin)

@@ -207,10 +207,16 @@ class AutoencoderKL:
     @classmethod
     def from_pretrained(cls, path, device="cuda:0", variant="fp16"):
         from safetensors.torch import load_file
+        cfg = None
+        cf = os.path.join(path, "vae", "config.json")  # diffusers' AutoencoderKL config (the keys VaeConfig.from_any keeps)
+        if os.path.exists(cf):
+            import json
+            with open(cf) as fh:
+                cfg = VaeConfig.from_any(json.load(fh))
         for name in (f"diffusion_pytorch_model.{variant}.safetensors", "diffusion_pytorch_model.safetensors"):
             f = os.path.join(path, "vae", name)
             if os.path.exists(f):
-                return cls(device=device).load_state_dict(load_file(f))
+                return cls(cfg, device=device).load_state_dict(load_file(f))
         raise FileNotFoundError(f"no VAE weights under {path}/vae (expected diffusers safetensors)")
 
     def _build(self, sd):

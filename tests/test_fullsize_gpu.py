@@ -109,6 +109,32 @@ def test_pnp_step_properties_full_size(eng):
         assert torch.equal(on[3][bg_only], on[0][bg_only])
         last = m1[None].expand(4, -1, -1, -1)
         assert torch.equal(on[3][last], on[2][last])
+        # The composition loop's two reductions at the size bench.py times them at (pipeline.prune_source_tail / share_cfg_prefix ->
+        # unet.prune_source_tail / shared_prefix_chunks), on a Q/K-injection-only step: the source chunks' dead tail is not computed
+        # and the unconditional chunk shares the conditional chunk's prefix -- the two destination chunks against the five-chunk
+        # forward within the batch-independence tolerance above (the shared prefix runs at another row count, i.e. on other tiles)
+        z = dict(x)
+        for k in ("il1", "il"):
+            z[k] = x[k].clone()
+            z[k][4] = z[k][3]
+        pnp_utils.register_time_all(pipe, 861, masks)
+        five = _fwd(eng, z, 861.0)
+        assert not torch.equal(five[3], five[4])
+        eng.prune_source_tail = True
+        try:
+            tail = _fwd(eng, z, 861.0)
+            eng.shared_prefix_chunks = 2
+            both = _fwd(eng, z, 861.0)
+        finally:
+            eng.prune_source_tail, eng.shared_prefix_chunks = False, 0
+        pnp_utils.register_time_all(pipe, None, None)
+        assert not tail[:3].any() and not both[:3].any()  # (the loop never reads them: INTEGRATION.md)
+        for name, o_ in (("prune_source_tail", tail), ("prune_source_tail + shared prefix", both)):
+            d = (o_[3:].float() - five[3:].float()).abs().max() / five.float().abs().max()
+            rel = (o_[3:].float() - five[3:].float()).norm() / five[3:].float().norm()
+            print(f"full size, {name}: destination chunks max-abs/max {float(d):.2e}, rel-L2 {float(rel):.2e} vs the five-chunk forward"
+                  f"{' (bit-identical)' if torch.equal(o_[3:], five[3:]) else ''}")
+            assert torch.isfinite(o_).all() and d < 8e-3 and rel < 5e-3, (name, float(d), float(rel))
         with pytest.raises(RuntimeError, match="UNet batch"):
             pnp_utils.register_time_all(pipe, 981, masks)
             _fwd(eng, _inputs(2))

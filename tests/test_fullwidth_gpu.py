@@ -174,6 +174,28 @@ def test_ext_forward_with_all_hooks_full_width(pair, trio):
             print(f"full-width ext forward, prune_source_tail: destination chunks rel-L2 {rel:.2e} vs oracle, {rel5:.2e} vs the "
                   f"five-chunk forward{' (bit-identical)' if torch.equal(tail[3:], out[3:]) else ''}")
             assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD and rel5 < 1e-3, (rel, mx, rel5)
+    # Sub-pixel form of Upsample2D + conv at C = 1 280 (`up_blocks[1]`: in every production batch-5 step 400 tiles; at this test's
+    # 20 images of 8 x 8 a grid of 100 tiles, which the >= 200-tile gate of ops.conv3x3 sends to the 9-tap form): gate forced open,
+    # the same forward against the oracle -- the launches are spied so that the test cannot pass with the gate still closed
+    from mvoc_amd import ops
+    seen = []
+    real_gemm, real_min = ops._gemm, ops.SUBPIXEL_MIN_TILES
+
+    def spy(d, *a, **kw):
+        if d.upsample == 2:
+            seen.append((d.cin, d.m))
+        return real_gemm(d, *a, **kw)
+
+    ops._gemm, ops.SUBPIXEL_MIN_TILES = spy, 0
+    try:
+        sub = eng.forward_ext(x["sample"], t, x["fps"], x["il1"], x["il"], x["ie"], x["eh"])[0]
+    finally:
+        ops._gemm, ops.SUBPIXEL_MIN_TILES = real_gemm, real_min
+    assert (1280, 5 * f * 16 * 16) in seen and (640, 5 * f * 32 * 32) in seen, seen
+    rel, mx = _metrics(sub, ref)
+    rels, _ = _metrics(sub, out)
+    print(f"full-width ext forward, C = 1 280 upsampler in sub-pixel form: rel-L2 {rel:.2e} vs oracle, {rels:.2e} vs the 9-tap form")
+    assert rel <= REL_L2_FWD and mx <= MAX_ABS_FWD and rels <= REL_L2_FWD, (rel, mx, rels)
     # shared_prefix_chunks (the composition loop's setting under classifier-free guidance): the unconditional and the conditional
     # chunk enter with the same latent / image latents / fps and differ in the prompt + CLIP-image embeddings only -- the engine
     # computes their common prefix (everything up to the first cross-attention) once

@@ -3,6 +3,7 @@
 import os
 import sys
 import re
+import numpy as np
 import types
 
 import pytest
@@ -294,3 +295,23 @@ def test_clip_pixel_values_match_the_feature_extractor():
     a, b = clip_pixel_values(frames), clip_ref.pixel_values(frames)
     assert a.shape == (3, 3, 224, 224) and a.dtype == torch.float32
     assert (a - b).abs().max() < 1e-6
+
+
+def test_unet_config_from_the_checkpoints_config_json():
+    """``<ckpt>/unet/config.json`` as diffusers 0.27.2 writes it (I2VGenXLUNet.register_to_config keys) -> UNetConfig: unknown keys
+    dropped, a per-block attention_head_dim list collapsed, another model class refused (reference door: inverse.py:113-118)"""
+    from mvoc_amd.unet_spec import UNetConfig, param_shapes
+    d = {"_class_name": "I2VGenXLUNet", "_diffusers_version": "0.27.2", "sample_size": 32, "in_channels": 4, "out_channels": 4,
+         "down_block_types": ["CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "DownBlock3D"],
+         "up_block_types": ["UpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D"],
+         "block_out_channels": [320, 640, 1280, 1280], "layers_per_block": 2, "norm_num_groups": 32, "cross_attention_dim": 1024,
+         "attention_head_dim": [64, 64, 64, 64], "num_attention_heads": None}
+    c = UNetConfig.from_diffusers(d)
+    assert c.__dict__ == UNetConfig().__dict__  # the published I2VGen-XL config IS the default
+    assert sum(int(np.prod(s)) for s in param_shapes(c).values()) == sum(int(np.prod(s)) for s in param_shapes(UNetConfig()).values())
+    small = UNetConfig.from_diffusers(dict(d, block_out_channels=[64, 128, 128, 128], cross_attention_dim=64, attention_head_dim=64))
+    assert small.block_out_channels == (64, 128, 128, 128) and small.cross_attention_dim == 64
+    with pytest.raises(ValueError):
+        UNetConfig.from_diffusers(dict(d, _class_name="UNet3DConditionModel"))
+    with pytest.raises(ValueError):
+        UNetConfig.from_diffusers(dict(d, attention_head_dim=[64, 64, 32, 64]))

@@ -986,15 +986,19 @@ def test_gemm_row_moments_and_layernorm_statistics_from_them(ops, m, n, k, resid
     assert getattr(ops.linear(x, w, b, resid=None, tile=tile, split_k=1, n_store=n - 64, rowmom=True), "row_moments", None) is None
 
 
-@pytest.mark.parametrize("nsample,rows,c,n,sums", [(6, 1024, 320, 320, False), (2, 4096, 320, 320, True), (20, 256, 128, 128, False),
-                                                  (1, 8192, 64, 64, True)])
-def test_groupnorm_folded_into_xs_linear(ops, nsample, rows, c, n, sums):
+@pytest.mark.parametrize("nsample,rows,c,n,sums,offset", [(6, 1024, 320, 320, False, 1.0), (2, 4096, 320, 320, True, 1.0), (20, 256, 128, 128, False, 1.0),
+                                                         (1, 8192, 64, 64, True, 1.0), (3, 2048, 320, 320, False, 20.0), (2, 4096, 320, 320, True, 20.0)])
+def test_groupnorm_folded_into_xs_linear(ops, nsample, rows, c, n, sums, offset):
     """GN -> proj_in with the norm folded into per-sample weights (mvoc_groupnorm_fold_xs_f16 + mvoc_xs_desc.wp_set_rows): against
-    fp32 torch and against the GroupNorm kernels followed by the same linear; statistics from the producer's channel sums too"""
+    fp32 torch and against the GroupNorm kernels followed by the same linear; statistics from the producer's channel sums too.
+    ``offset`` 20: group means 20-40 sigma off zero (offset / outlier channels of a residual stream) -- the folded constant takes its mean
+    term from the ROUNDED scaled weight, so the weights' fp16 rounding meets |x - mean|, not |mean| (norm.hip: gn_fold_xs_kernel)"""
     g = torch.Generator().manual_seed(nsample * rows + c)
     m = nsample * rows
     x = torch.randn(m, c, generator=g) * (0.5 + torch.rand(nsample, 1, c, generator=g).repeat(1, rows, 1).reshape(m, c)) + \
         torch.randn(nsample, 1, c, generator=g).repeat(1, rows, 1).reshape(m, c)
+    if offset != 1.0:  # one offset per (sample, GROUP): the group's mean sits `offset` sigma off zero, its variance stays ~ 1
+        x = x + (offset * (1 + torch.rand(nsample, 1, 32, generator=g))).repeat_interleave(c // 32, 2).repeat(1, rows, 1).reshape(m, c)
     w = (torch.randn(n, c, generator=g) / c ** 0.5).half()
     b = torch.randn(n, generator=g).half()
     gm, bt = (1 + 0.3 * torch.randn(c, generator=g)).half(), (0.3 * torch.randn(c, generator=g)).half()

@@ -530,6 +530,15 @@ def test_bench_gpus2_launched_plainly_on_the_gpu(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "2 independent shards" in j["config"]["parallelism"]
     assert "3 concurrent source clip(s) per rank" in j["config"]["parallelism"]
+    # the line carries the evidence that N ranks ran: one row per rank (device identity, the rank's own clock) and the world size
+    # the collective backend saw; without MVOC_BENCH_OVERSUBSCRIBE two ranks on one device are refused before anything is timed
+    ranks = j["config"]["ranks"]
+    assert [r_["rank"] for r_ in ranks] == [0, 1] and len({r_["pid"] for r_ in ranks}) == 2
+    assert all(r_["device_name"] and r_["ms_per_step"] > 0 and r_["ms_per_step"] <= j["ms_per_step"] * 1.001 for r_ in ranks)
+    assert j["config"]["collective_backend"]["world_size"] == 2
+    env.pop("MVOC_BENCH_OVERSUBSCRIBE")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0 and ("visible" in r.stderr + r.stdout or "distinct device" in r.stderr + r.stdout)
 
 
 def test_fifty_step_inversion_drift_vs_oracle():
