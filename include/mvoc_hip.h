@@ -108,6 +108,14 @@ typedef struct mvoc_gemm_desc {
                            concurrent loops), so an under-filled grid need not be split over K to fill the chip.  Clamped to 8.  It
                            changes the tile / split-K choice, hence the summation order of a launch (results differ from the unhinted
                            launch by fp16 rounding of another order, never by more); per call, no process-wide state. */
+  int32_t k_order;      /* conv3x3 / temporal3 only.  0: `w` is tap-major, k = tap * cin + c (above).  1: CHANNEL-CHUNK-major with the taps
+                           innermost, k = (c / 64) * (ntaps * 64) + tap * 64 + c % 64 (ntaps = 9 / 3; mvoc_amd.ops.chunk_major_weights):
+                           the nine (three) taps of one 64-channel slab of the source are consumed back to back, so the re-reads a block
+                           makes of its own pixel rows (each source line is read once per tap: F.conv2d at pnp_utils.py:939, 968, conv3d at
+                           :1042-1057) are ~50 KB apart instead of a whole tap's cin * 256 rows and hit the XCD's L2.  Same products, same
+                           fp32 sums in another order (exact on integer operands).  Needs cin, c1 multiples of 64, no upsample, and the
+                           eight-phase tiles (m >= 1024, 16-byte addressable operands < 2 GB): anything else is an error (-2), not a
+                           fall-back -- the caller holds the tap-major weights for those launches. */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);

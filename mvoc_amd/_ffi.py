@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("upsample", i32), ("hup", i32), ("wup", i32), ("frames", i32), ("hw", i32), ("act", i32), ("tile", i32),
                 ("split_k", i32), ("workspace", vp), ("workspace_bytes", sz), ("ln_rowsum", vp), ("ln_bias", vp),
                 ("ln_eps", f32), ("pad_mode", i32), ("ln_stats", vp), ("chan_sums", vp), ("row_moments", vp),
-                ("row_moments_ld", i32), ("concurrency", i32)]
+                ("row_moments_ld", i32), ("concurrency", i32), ("k_order", i32)]
 
 
 class AttnDesc(C.Structure):

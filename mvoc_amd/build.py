@@ -13,6 +13,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LAB = os.environ.get("MVOC_BUILD_LAB") == "1"  # diagnostic library (in-kernel stamps / ablations): libmvoc_hip_lab.so
 if LAB:
     LIB = os.path.join(HERE, "libmvoc_hip_lab.so")
+# A/B builds of one experiment: MVOC_BUILD_VARIANT=<name> MVOC_BUILD_DEFS="-DFOO=1 ..." -> libmvoc_hip_<name>.so beside the product library
+# (objects <src>.<name>.o); loaded with MVOC_HIP_LIB=<path> (mvoc_amd/_ffi.py).  Never the product build.
+VARIANT = os.environ.get("MVOC_BUILD_VARIANT", "")
+VARIANT_DEFS = os.environ.get("MVOC_BUILD_DEFS", "").split()
+if VARIANT:
+    LIB = os.path.join(HERE, f"libmvoc_hip_{VARIANT}.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage"]  # the remarks are kept per object (<obj>.res.txt): tests check them
 # attention: keep the MFMA accumulators in VGPRs (gfx950 has one unified register file).  In AGPR form hipcc time-shares
@@ -33,7 +39,7 @@ def _digest():
     for f in sorted(x for x in os.listdir(CSRC) if x.endswith((".hip", ".h"))) + ["../../include/mvoc_hip.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
+    h.update((" ".join(FLAGS + VARIANT_DEFS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -47,9 +53,9 @@ def build(force=False, verbose=True):
     shared = b"".join(open(os.path.join(CSRC, f), "rb").read() for f in sorted(os.listdir(CSRC)) if f.endswith(".h"))
     shared += open(os.path.join(HERE, "..", "include", "mvoc_hip.h"), "rb").read()
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".lab.o" if LAB else ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", f".{VARIANT}.o" if VARIANT else (".lab.o" if LAB else ".o")))
         objs.append(obj)
-        cmd = [HIPCC, *FLAGS, *(["-DMVOC_PP_LAB"] if LAB else []), *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *(["-DMVOC_PP_LAB"] if LAB else []), *VARIANT_DEFS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         # per-object digest (source + every header + the command line): unchanged translation units are not recompiled
         od = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + shared + " ".join(cmd).encode()).hexdigest()
         ostamp = obj + ".stamp"

@@ -982,6 +982,13 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                      (!d->rowadd || (((uintptr_t)d->rowadd & 15) == 0 && d->ld_rowadd % 8 == 0 && a.rowadd_div >= 64)) &&
                      // the folded-upsample instantiation carries the plain epilogue only (gemm8.hip: launch8)
                      (!d->upsample || (d->act == MVOC_ACT_NONE && !d->ln_rowsum));
+  if (d->k_order) {
+    MVOC_REQUIRE(d->k_order == 1 && d->a_mode != MVOC_A_PLAIN && !d->upsample && g8_ok && d->m >= 1024 && (tile == 0 || tile == 81 || tile == 82) &&
+                     d->k == (d->a_mode == MVOC_A_CONV3X3 ? 9 : 3) * (int64_t)d->cin,
+                 -2, "gemm: k_order = 1 (chunk-major K) is a conv3x3 / temporal3 form of the eight-phase tiles: cin, c1 %% 64 == 0, no "
+                     "upsample, m >= 1024, 16-byte addressable operands < 2 GB");
+    a.korder = 1;
+  }
   if (a.subpx) {
     MVOC_REQUIRE(g8_ok, -2, "gemm: the sub-pixel upsample conv runs on the eight-phase tiles only (k, cin %% 64 == 0, 16-byte addressable output)");
     tile = 81;
@@ -999,7 +1006,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     };
     const double e81 = eff(256, 1.0);
     const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.85) : 0.0;
-    if (e81 >= 0.55 || e82 >= 0.55) {
+    if (e81 >= 0.55 || e82 >= 0.55 || a.korder) {  // (chunk-major weights: these tiles or nothing -- the caller gates on the same model)
       tile = e82 > e81 ? 82 : 81;
     } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
       // deep K on a grid of 64..190 tiles (the 16x16 / 8x8 levels): K slices bring the grid to one block per CU; measured
@@ -1015,6 +1022,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       }
     }
   }
+  if (a.korder && tile != 81 && tile != 82) tile = 81;  // (k < 256: below the automatic choice's floor; still these tiles or nothing)
   if (tile == 0 && glds_ok) {
     // what the eight-phase tiles do not take: grids that fill less than ~55 % of the chip after quantisation, M < 1024, K < 256
     if (d->k <= 640 && d->m > 2048 && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {

@@ -279,8 +279,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
   if constexpr (AFF) rowoff[0][0] = row_m(0, 0) - (p.a_mode == MVOC_A_CONV3X3 ? p.wsrc + 1 : 0);
   // K position of the NEXT activation tile to issue (both Y halves of a tile are issued from the same position): all scalar
-  int ytap = kbeg / p.cin;
-  int ych0 = kbeg - ytap * p.cin;
+  // (p.korder, mvoc_gemm_desc.k_order = 1: K = (64-channel chunk, tap, 64) -- the tap changes with EVERY K tile and the channel
+  // chunk every ntaps tiles: a block's nine reads of a pixel row's 128-byte slab follow each other within nine K tiles)
+  const int ntaps = p.a_mode == MVOC_A_CONV3X3 ? 9 : 3;
+  int ytap, ych0;
+  if (p.korder) {
+    const int ck = kbeg / (ntaps * 64);
+    ytap = (kbeg - ck * ntaps * 64) >> 6;
+    ych0 = ck * 64;
+  } else {
+    ytap = kbeg / p.cin;
+    ych0 = kbeg - ytap * p.cin;
+  }
   int yso = 0, yld2 = 0, ytaprows = 0;
   bool yre = true;
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)G8_OOB, 0x00020000);
@@ -322,6 +332,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     }
   };
   auto y_advance = [&]() {
+    if (p.korder) {
+      yre = true;
+      if (++ytap == ntaps) { ytap = 0; ych0 += 64; }
+      return;
+    }
     yso += 128;
     ych0 += 64;
     yre = ych0 == p.c1;

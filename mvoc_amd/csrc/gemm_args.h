@@ -43,6 +43,7 @@ struct GemmArgs {
   // sp_rows) are the source pixels (img, i, j) of phase ph = 2 a + b; their outputs go to pixel (2 i + a, 2 j + b); w holds the four
   // phase kernels [4][N][4 cin]
   int subpx, sp_rows;
+  int korder;   // gemm8, conv / temporal: K runs (64-channel chunk, tap, 64) instead of (tap, channel): mvoc_gemm_desc.k_order
   int epi_lds;  // outputs / residual are 16-byte addressable per 8-channel chunk: LDS-transposed epilogue
 };
 

@@ -161,6 +161,52 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
     return out
 
 
+# ---- chunk-major K order of the conv / temporal-conv weights (include/mvoc_hip.h: mvoc_gemm_desc.k_order) -----------------------------------
+K_ORDER_CHUNK = os.environ.get("MVOC_KORDER", "0") != "0"
+_CHUNK_CACHE = {}
+
+
+def chunk_major_weights(w, ntaps):
+    """tap-major conv weights [N, ntaps * cin] (k = tap * cin + c; unet.pack_conv3x3 / pack_tconv) -> chunk-major
+    [N, (cin / 64) * ntaps * 64] (k = (c / 64) * ntaps * 64 + tap * 64 + c % 64).  Built once per weight tensor and kept (the weights
+    of a loaded network are persistent; the cache holds a reference to the source so its address cannot be reused)."""
+    key = (w.data_ptr(), tuple(w.shape), ntaps)
+    hit = _CHUNK_CACHE.get(key)
+    if hit is not None and hit[0] is w:
+        return hit[1]
+    n, k = w.shape
+    cin = k // ntaps
+    if k != ntaps * cin or cin % 64:
+        raise RuntimeError(f"chunk_major_weights: k = {k} is not {ntaps} taps of a multiple of 64 channels")
+    wc = w.view(n, ntaps, cin // 64, 64).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+    _CHUNK_CACHE[key] = (w, wc)
+    return wc
+
+
+def _g8_fills(m, n, conc, geglu=False):
+    """gemm.hip's choice of the eight-phase tiles for an un-forced launch (the `eff` model there): True when the 256- or the 320-wide grid
+    fills >= 55 % of the chip after quantisation"""
+    def eff(bx, rate):
+        nt = (n + bx - 1) // bx
+        blocks = ((m + 255) // 256) * nt * conc
+        return n / (nt * bx) * blocks / (((blocks + 255) // 256) * 256) * rate
+    return eff(256, 1.0) >= 0.55 or (not geglu and n % 320 == 0 and eff(320, 0.85) >= 0.55)
+
+
+def _chunk_ok(d, x, x2, w, out, bias, resid, rowadd, ntaps, rows_a):
+    """mirror of gemm.hip's g8_ok for a conv / temporal launch + the grid-fill rule: a k_order = 1 request the library cannot place on
+    the eight-phase tiles is an error there (the caller holds the tap-major weights), so it is only made where it will be taken"""
+    lim = 1 << 31
+    al = lambda t: t is None or t.data_ptr() % 16 == 0
+    return (K_ORDER_CHUNK and d.cin % 64 == 0 and d.c1 % 64 == 0 and d.k == ntaps * d.cin and d.m >= 1024 and d.tile in (0, 81, 82) and not d.upsample
+            and d.split_k <= 1 and d.pad_mode == 0
+            and out.stride(0) % 8 == 0 and d.n_store % 8 == 0 and al(out) and al(bias) and al(resid) and al(rowadd)
+            and (resid is None or resid.stride(0) % 8 == 0) and (rowadd is None or (rowadd.stride(0) % 8 == 0 and d.rowadd_div >= 64))
+            and rows_a * x.stride(0) * 2 < lim and (x2 is None or rows_a * x2.stride(0) * 2 < lim) and w.shape[0] * d.k * 2 < lim
+            and d.m * out.stride(0) * 2 < lim and (resid is None or d.m * resid.stride(0) * 2 < lim)
+            and (d.tile != 0 or _g8_fills(d.m, w.shape[0], _CONCURRENCY.n)))
+
+
 SUBPIXEL_MIN_TILES = 200  # the sub-pixel form of Upsample2D + conv needs a grid that fills the chip; under it the 9-tap split-K form
 #                           stays (8 -> 16 at batch 1).  Tests set 0 to put every upsampler of a small forward on the sub-pixel form.
 
@@ -207,6 +253,8 @@ def conv3x3(x, w, bias, *, nimg, h, wd, x2=None, stride=1, upsample_to=None, row
             raise RuntimeError("conv3x3: w_subpixel must be pack_conv3x3_subpixel() of the same kernel")
         d.upsample, d.w, d.k, d.split_k = 2, w_subpixel.data_ptr(), 4 * cin, 1
         sums = False
+    elif _chunk_ok(d, x, x2, w, out, bias, resid, rowadd, 9, nimg * h * wd):
+        d.w, d.k_order, d.split_k = chunk_major_weights(w, 9).data_ptr(), 1, 1
     _gemm(d, x.device, out, sums)
     return out, ho, wo
 
@@ -225,6 +273,8 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     d.c1 = d.cin = x.shape[1]
     d.frames, d.hw = frames, hw
     d.split_k = split_k
+    if _chunk_ok(d, x, None, w, out, bias, resid, None, 3, m):
+        d.w, d.k_order, d.split_k = chunk_major_weights(w, 3).data_ptr(), 1, 1
     _gemm(d, x.device, out, sums)
     return out
 

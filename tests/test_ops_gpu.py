@@ -327,6 +327,92 @@ def test_conv3x3_production_tiles_exact(ops, case, tile):
     assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
 
 
+class _chunk_major:
+    """``with _chunk_major(ops) as seen:`` -- conv / temporal launches take the chunk-major K order (mvoc_gemm_desc.k_order = 1) where
+    ops gates it in; ``seen`` collects the k_order of every GEMM launch so that a test cannot pass on the tap-major path"""
+
+    def __init__(self, ops):
+        self.ops = ops
+
+    def __enter__(self):
+        o = self.ops
+        self.saved = (o._gemm, o.K_ORDER_CHUNK)
+        seen = []
+        real = o._gemm
+
+        def spy(d, *a, **kw):
+            seen.append(int(d.k_order))
+            return real(d, *a, **kw)
+
+        o._gemm, o.K_ORDER_CHUNK = spy, True
+        return seen
+
+    def __exit__(self, *exc):
+        self.ops._gemm, self.ops.K_ORDER_CHUNK = self.saved
+
+
+@pytest.mark.parametrize("tile", [0, 81, 82])
+@pytest.mark.parametrize("case", ["conv640_320", "conv1280+640_640"])
+def test_conv3x3_chunk_major_k_order_exact(ops, case, tile):
+    """K = (64-channel chunk, tap, 64) with host-repacked weights (include/mvoc_hip.h: k_order): the same products summed in another
+    order -- exact on integer operands; one and two sources (the chunk index runs over the concatenated channel axis), row-add,
+    residual, image borders inside tiles"""
+    from mvoc_amd.unet import pack_conv3x3
+    c, ref = _prod_case(case)
+    # (tile 0 = the library's own choice: the test shapes are a 16th of the production batch, so the grid-fill rule that gates the
+    # chunk-major form is met through the concurrency hint, as eight such launches side by side would)
+    with _chunk_major(ops) as seen, ops.gemm_concurrency(8 if tile == 0 else 1):
+        out, _, _ = ops.conv3x3(c["x1"], pack_conv3x3(c["wt"]), c["b"], nimg=c["n"], h=c["h"], wd=c["w"], x2=c["x2"], rowadd=c["temb"],
+                                rowadd_div=c["fr"] * c["h"] * c["w"], resid=c["res"], n_store=c["cout"], tile=tile)
+    assert seen == [1], seen
+    assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+
+
+@pytest.mark.parametrize("stride,hw", [(2, 32), (1, 24)])
+def test_conv3x3_chunk_major_stride_and_ragged_rows(ops, stride, hw):
+    """the non-affine gather (stride 2: Downsample2D) and an M that is not a multiple of the 256-pixel tile, chunk-major"""
+    from mvoc_amd.unet import pack_conv3x3
+    g = torch.Generator().manual_seed(7 + stride)
+    n, cin, cout = 5, 128, 320
+    x = _ints(g, (n, cin, hw, hw))
+    wt = _ints(g, (cout, cin, 3, 3))
+    wt[torch.rand(wt.shape, generator=g) < 0.5] = 0
+    b = _ints(g, (cout,), -4, 4)
+    ref = F.conv2d(x, wt, b, padding=1, stride=stride)
+    assert ref.abs().max() < 2048
+    with _chunk_major(ops) as seen:
+        out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=hw, wd=hw, stride=stride, n_store=cout, tile=81)
+    assert seen == [1] and (ho, wo) == tuple(ref.shape[2:])
+    assert torch.equal(out.float().cpu(), _nhwc(ref))
+
+
+@pytest.mark.parametrize("tile", [0, 81, 82])
+def test_tconv3_chunk_major_k_order_exact(ops, tile):
+    from mvoc_amd.unet import pack_tconv
+    test_tconv3_production_tiles_exact(ops, 81)  # (fills the case cache)
+    c, ref = _prod_cache["tconv640"]
+    with _chunk_major(ops) as seen, ops.gemm_concurrency(8 if tile == 0 else 1):
+        out = ops.tconv3(c["rows"], pack_tconv(c["wt"]), c["b"], nvid=c["nb"], frames=c["frames"], hw=c["hw"], resid=c["rows"], tile=tile)
+    assert seen == [1], seen
+    assert torch.equal(out.float().cpu(), ref), f"tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
+
+
+def test_chunk_major_request_outside_the_eight_phase_tiles_is_an_error(ops):
+    """k_order = 1 is a form of the eight-phase tiles: a request they cannot take fails loudly (the library never reads chunk-major
+    weights with a tap-major kernel)"""
+    from mvoc_amd._ffi import GemmDesc, lib
+    import ctypes as C
+    x = torch.zeros(512, 64, dtype=torch.float16, device="cuda")
+    w = torch.zeros(64, 576, dtype=torch.float16, device="cuda")
+    out = torch.empty(512, 64, dtype=torch.float16, device="cuda")
+    d = GemmDesc()
+    d.a, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.m, d.n, d.k, d.n_store, d.ldo, d.lda, d.c1, d.cin = 512, 64, 576, 64, 64, 64, 64, 64
+    d.a_mode, d.nimg, d.hout, d.wout, d.hsrc, d.wsrc, d.stride, d.k_order = 1, 2, 16, 16, 16, 16, 1, 1
+    assert lib.mvoc_gemm_f16(C.byref(d), torch.cuda.current_stream().cuda_stream) == -2  # m < 1024
+    assert b"k_order" in lib.mvoc_last_error()
+
+
 @pytest.mark.parametrize("tile", [81, 82])
 @pytest.mark.parametrize("split_k", [2, 4])
 def test_g8_split_k_exact(ops, split_k, tile):

@@ -8,7 +8,8 @@
      composition step (UNet with the PnP hooks of a Q/K-injection step + CFG + DDIM update) at 16 x 64 x 64, at the sweep's best
      thread count -> job-mix steps/s = 4 / (3 t_B1 + t_B5) -> profiles/r6/cpu_baseline_cfg2_measured.json
 
-CPU only (no GPU call); ~10 min of host time.  usage: python3 tools/cpu_baseline_full.py <outdir> [--skip-b5]"""
+CPU only (no GPU call); the sweep ~20 min (256 threads: 300 s per step), the cfg-2 steps ~8 min.
+usage: python3 tools/cpu_baseline_full.py <outdir> [--skip-b5] [--threads N: that thread count only, no sweep file]"""
 import json
 import os
 import sys
@@ -88,8 +89,9 @@ def cfg1_step():
 sweep = []
 lines = [f"host: {host} hardware threads, {cpu_model()}; torch {torch.__version__}; one cfg-1 inversion step (B = 1, {f1} frames, {hw1} x {hw1} latents, "
          f"{fl1 / 1e12:.2f} TFLOP) on the oracle (fp32 PyTorch CPU ops), 1 warm-up + 2 measured", "threads  s/step (two runs)   TFLOP/s"]
+FIXED = int(sys.argv[sys.argv.index("--threads") + 1]) if "--threads" in sys.argv else 0  # skip the sweep (it was taken before)
 for th in (8, 16, 32, 64, 128, 256):
-    if th > host:
+    if th > host or (FIXED and th != FIXED):
         continue
     torch.set_num_threads(th)
     ts = timed(cfg1_step)
@@ -99,7 +101,8 @@ for th in (8, 16, 32, 64, 128, 256):
     print(lines[-1], flush=True)
 best_th = max(sweep, key=lambda r: r["tflops"])["threads"]
 lines.append(f"best: {best_th} threads")
-open(f"{out}/cpu_threads.txt", "w").write("\n".join(lines) + "\n")
+if not FIXED:
+    open(f"{out}/cpu_threads.txt", "w").write("\n".join(lines) + "\n")
 
 # ---- 2. cfg 2 at full size ----------------------------------------------------------------------------------------------------
 torch.set_num_threads(best_th)

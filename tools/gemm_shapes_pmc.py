@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-SHAPE counters of the implicit-GEMM family (GPU box; driven by tools/pmc_shapes.sh, one rocprofv3 --pmc pass per counter
 set): records every implicit-GEMM launch of one UNet forward at batch B, keeps the TOP shapes by flops x count, and launches each
-REPS times behind a marker kernel (mvoc_delay_us) -- the rows between two markers of the counter CSV are that shape's dispatches
+REPS times between two marker kernels (mvoc_delay_us) -- the rows between an opening and its closing marker of the counter CSV are that shape's dispatches
 (a split-K call = its slab kernel + its reduce kernel).  Without a profiler around it the same script times every shape with HIP
 events and writes the manifest the passes are merged against.
 
@@ -38,7 +38,7 @@ orig = ops._gemm
 
 
 def spy(d, dev=None, *rest, **kw):
-    key = (d.a_mode, d.m, d.n, d.k, d.cin, d.c1, d.stride, d.upsample, d.act, bool(d.resid), bool(d.rowadd), d.hout, bool(d.ln_rowsum))
+    key = (d.a_mode, d.m, d.n, d.k, d.cin, d.c1, d.stride, d.upsample, d.act, bool(d.resid), bool(d.rowadd), d.hout, bool(d.ln_rowsum), int(d.k_order))
     if key not in rec:
         dd = _ffi.GemmDesc()
         C.memmove(C.byref(dd), C.byref(d), C.sizeof(d))
@@ -80,25 +80,28 @@ for key, (d, cnt) in sel:
             setattr(d, f_, stats.data_ptr())
     if d.ln_stats:  # {mean, rstd} per row: zeros / anything finite
         d.ln_stats = stats.data_ptr()
-    if d.workspace:
+    # (the spy copied the descriptor before ops._gemm attached its split-K scratch: same rule as there)
+    d.workspace, d.workspace_bytes = None, 0
+    if d.act != 1 and d.split_k != 1 and _ffi.lib.mvoc_gemm_workspace_bytes(d.m, d.n, d.k):
         d.workspace, d.workspace_bytes = wsbuf.data_ptr(), wsbuf.numel() * 4
     for _ in range(2):
         orig(d)
     torch.cuda.synchronize()
-    _ffi.lib.mvoc_delay_us(1, stream)  # marker
+    _ffi.lib.mvoc_delay_us(1, stream)  # opening marker: the REPS launches of this shape sit between it and the closing marker
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(REPS):
         orig(d)
     e1.record()
+    _ffi.lib.mvoc_delay_us(1, stream)  # closing marker (the next shape's warm-up launches follow it)
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / REPS * 1e3
     rows_a = d.m if d.a_mode != 1 else d.nimg * d.hsrc * d.wsrc
     # compulsory bytes: source rows once + weights + stored outputs (+ residual)
-    alg = 2 * (rows_a * d.cin if d.a_mode else d.m * d.k) + 2 * d.n * d.k + 2 * d.m * d.n_store * (0.5 if d.act == 1 else 1) + (2 * d.m * d.n_store if d.resid else 0)
+    ns = d.n // 2 if d.act == 1 else (d.n_store or d.n)
+    alg = 2 * (rows_a * d.cin if d.a_mode else d.m * d.k) + 2 * d.n * d.k + 2 * d.m * ns * (2 if d.resid else 1)
     manifest.append({"mode": d.a_mode, "M": d.m, "N": d.n, "K": d.k, "cin": d.cin, "c1": d.c1, "act": d.act, "resid": bool(d.resid), "upsample": d.upsample,
-                     "ln": bool(d.ln_rowsum), "count": cnt, "reps": REPS, "us": us, "flop": 2.0 * d.m * d.n * d.k, "alg_bytes": alg})
-_ffi.lib.mvoc_delay_us(1, stream)
+                     "ln": bool(d.ln_rowsum), "korder": int(d.k_order), "count": cnt, "reps": REPS, "us": us, "flop": 2.0 * d.m * d.n * d.k, "alg_bytes": alg})
 torch.cuda.synchronize()
 tag = os.environ.get("MVOC_PMC_PASS", "time")
 json.dump(manifest, open(f"{out}/manifest_{tag}.json", "w"), indent=0)

@@ -34,11 +34,11 @@ for p in sorted(glob.glob(f"{out}/p*/")):
         disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
     ids = sorted(disp)
     marks = [i for i in ids if "delay_kernel" in disp[i][0]["Kernel_Name"]]
-    marks = marks[-(len(man) + 1):]
-    assert len(marks) == len(man) + 1, (p, len(marks), len(man))
+    marks = marks[-2 * len(man):]  # (opening, closing) per shape; what lies between a closing and the next opening is warm-up
+    assert len(marks) == 2 * len(man), (p, len(marks), len(man))
     for s in range(len(man)):
         for i in ids:
-            if marks[s] < i < marks[s + 1]:
+            if marks[2 * s] < i < marks[2 * s + 1]:
                 r0 = disp[i][0]
                 if "at::native" in r0["Kernel_Name"]:
                     continue
@@ -48,7 +48,7 @@ for p in sorted(glob.glob(f"{out}/p*/")):
                     dur[s] += (int(r0["End_Timestamp"]) - int(r0["Start_Timestamp"])) * 1e-9
                     names[s][r0["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]] += 1
 tab = []
-print(f"{'mode':4} {'M':>7} {'N':>6} {'K':>6} {'cin':>5} act res cnt | {'us':>7} {'TF/s':>5} | {'alg MB':>7} {'fetch':>7} {'write':>7} {'ratio':>5} | {'MFMA%':>5} {'wait%':>5} {'GHz':>5} {'L2hit%':>6} | kernel")
+print(f"{'mode':4}{'ko':>2} {'M':>7} {'N':>6} {'K':>6} {'cin':>5} act res cnt | {'us':>7} {'TF/s':>5} | {'alg MB':>7} {'fetch':>7} {'write':>7} {'ratio':>5} | {'MFMA%':>5} {'wait%':>5} {'GHz':>5} {'L2hit%':>6} | kernel")
 for s, m in enumerate(man):
     c, reps = per[s], m["reps"]
     fetch = c.get("FETCH_SIZE", 0) * 2048 / reps
@@ -62,7 +62,7 @@ for s, m in enumerate(man):
     row = dict(m, fetch_bytes=fetch, write_bytes=write, traffic_ratio=(fetch + write) / m["alg_bytes"], mfma_busy_pct=busy, wait_pct=wait, held_ghz=ghz, l2_hit_pct=hit, kernels=kn,
                tflops=m["flop"] / m["us"] / 1e6)
     tab.append(row)
-    print(f"{m['mode']:4d} {m['M']:7d} {m['N']:6d} {m['K']:6d} {m['cin']:5d} {m['act']:3d} {int(m['resid']):3d} {m['count']:3d} | {m['us']:7.1f} {row['tflops']:5.0f} | "
+    print(f"{m['mode']:4d}{m.get('korder', 0):2d} {m['M']:7d} {m['N']:6d} {m['K']:6d} {m['cin']:5d} {m['act']:3d} {int(m['resid']):3d} {m['count']:3d} | {m['us']:7.1f} {row['tflops']:5.0f} | "
           f"{m['alg_bytes'] / 1e6:7.1f} {fetch / 1e6:7.1f} {write / 1e6:7.1f} {row['traffic_ratio']:5.2f} | {busy:5.1f} {wait:5.1f} {ghz:5.2f} {hit:6.1f} | {kn}")
 tw = sum(r["us"] * r["count"] for r in tab)
 print(f"time-weighted over these {len(tab)} shapes ({tw / 1e3:.1f} ms per forward): traffic ratio "
