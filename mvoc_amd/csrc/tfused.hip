@@ -35,12 +35,8 @@ struct TfArgs {
   unsigned long long* stamps;  // diagnostic builds only
 };
 
-// TF_SETPRIO (build-time experiment, round 6): the wave raises its issue priority over its SIMD partner -- a wave of the CU's OTHER
-// block, in its vector-only epilogue -- for the 20 MFMAs of a stage.
-#ifndef TF_SETPRIO
-#define TF_SETPRIO 0
-#endif
-
+// (round 6: s_setprio(1) around the 20 MFMAs of a stage -- the wave against its SIMD partner, a wave of the CU's OTHER block in its
+// vector-only epilogue -- moved nothing: 292 -> 294-297 us at batch 5, profiles/r6/tfused_setprio_ab.txt; not kept)
 template <int N>
 __device__ __forceinline__ void tf_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -207,9 +203,6 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
 #pragma unroll
       for (int i = 0; i < PD; ++i) wf[i] = *reinterpret_cast<const half8_t*>(wl + i * 1024);
       __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
-#if TF_SETPRIO
-      __builtin_amdgcn_s_setprio(TF_SETPRIO);
-#endif
 #pragma unroll
       for (int s = 0; s < NK; ++s) {
         acc = w_rows ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s % PD], xf[s], acc, 0, 0, 0)
@@ -218,9 +211,6 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-#if TF_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       ++stage;
       return;
     }

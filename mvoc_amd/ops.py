@@ -162,7 +162,8 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
 
 
 # ---- chunk-major K order of the conv / temporal-conv weights (include/mvoc_hip.h: mvoc_gemm_desc.k_order) -----------------------------------
-K_ORDER_CHUNK = os.environ.get("MVOC_KORDER", "0") != "0"
+K_ORDER_CHUNK = os.environ.get("MVOC_KORDER", "1") != "0"
+K_ORDER_FORCE_256 = False  # tests: a forced tile 81 takes the chunk-major form too (exactness of the 256-wide kernel's path)
 _CHUNK_CACHE = {}
 
 
@@ -183,14 +184,18 @@ def chunk_major_weights(w, ntaps):
     return wc
 
 
-def _g8_fills(m, n, conc, geglu=False):
-    """gemm.hip's choice of the eight-phase tiles for an un-forced launch (the `eff` model there): True when the 256- or the 320-wide grid
-    fills >= 55 % of the chip after quantisation"""
+def _g8_choice(m, n, conc, geglu=False):
+    """gemm.hip's choice for an un-forced launch (the `eff` model there): 82 / 81 when the 320- / 256-wide eight-phase grid fills
+    >= 55 % of the chip after quantisation and prices better, else 0 (another tile family takes the launch)"""
     def eff(bx, rate):
         nt = (n + bx - 1) // bx
         blocks = ((m + 255) // 256) * nt * conc
         return n / (nt * bx) * blocks / (((blocks + 255) // 256) * 256) * rate
-    return eff(256, 1.0) >= 0.55 or (not geglu and n % 320 == 0 and eff(320, 0.85) >= 0.55)
+    e81 = eff(256, 1.0)
+    e82 = eff(320, 0.85) if (not geglu and n % 320 == 0) else 0.0
+    if e81 < 0.55 and e82 < 0.55:
+        return 0
+    return 82 if e82 > e81 else 81
 
 
 def _chunk_ok(d, x, x2, w, out, bias, resid, rowadd, ntaps, rows_a):
@@ -204,7 +209,13 @@ def _chunk_ok(d, x, x2, w, out, bias, resid, rowadd, ntaps, rows_a):
             and (resid is None or resid.stride(0) % 8 == 0) and (rowadd is None or (rowadd.stride(0) % 8 == 0 and d.rowadd_div >= 64))
             and rows_a * x.stride(0) * 2 < lim and (x2 is None or rows_a * x2.stride(0) * 2 < lim) and w.shape[0] * d.k * 2 < lim
             and d.m * out.stride(0) * 2 < lim and (resid is None or d.m * resid.stride(0) * 2 < lim)
-            and (d.tile != 0 or _g8_fills(d.m, w.shape[0], _CONCURRENCY.n)))
+            # Measured (profiles/r6/gemm_per_shape_pmc_korder.txt): FETCH falls 3-7 x on every conv (L2 hit rate 52 -> 85-92 %) and the
+            # held clock rises; the 320-wide tile, whose activation offsets are formed at issue time anyway, gains (temporal K = 960:
+            # - 8 %); the 256-wide tile pays for rebuilding its four offset registers EVERY K tile with 12-18 % -- so: the 320-wide
+            # tile on an affine gather (the only form launch8 sends to it), nothing else, unless a test forces tile 81
+            and ((d.tile == 82 or (d.tile == 0 and _g8_choice(d.m, w.shape[0], _CONCURRENCY.n) == 82))
+                 and (d.a_mode != A_CONV3X3 or (d.stride == 1 and d.hsrc == d.hout and d.wsrc == d.wout))
+                 or d.tile == 81 and K_ORDER_FORCE_256))
 
 
 SUBPIXEL_MIN_TILES = 200  # the sub-pixel form of Upsample2D + conv needs a grid that fills the chip; under it the 9-tap split-K form

@@ -344,11 +344,12 @@ class _chunk_major:
             seen.append(int(d.k_order))
             return real(d, *a, **kw)
 
-        o._gemm, o.K_ORDER_CHUNK = spy, True
+        o._gemm, o.K_ORDER_CHUNK, o.K_ORDER_FORCE_256 = spy, True, True
         return seen
 
     def __exit__(self, *exc):
         self.ops._gemm, self.ops.K_ORDER_CHUNK = self.saved
+        self.ops.K_ORDER_FORCE_256 = False
 
 
 @pytest.mark.parametrize("tile", [0, 81, 82])

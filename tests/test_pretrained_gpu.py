@@ -107,6 +107,7 @@ def test_inverse_py_without_synthetic_reads_the_checkpoint(tmp_path, monkeypatch
         tmpl.inverse_config.prompt = "sailboat,ocean"  # goes through the checkpoint's tokenizer + text tower
         entries = [{"active": True, "video_name": "clipA", "video_dir": str(tmp_path / "demo" / "clipA"), "image_size": [64, 64], "n_frames": 4,
                     "recon_config": {"enable_recon": True, "ddim_init_latents_t_idx": 1}}]
+        inverse.seed_everything(tmpl.seed)  # as the driver's __main__ does: the VAE samples its latent distribution from the global RNG
         inverse.main(tmpl, entries, torch.device("cuda:0"), synthetic=False, concurrent_entries=1)
         return tmp_path / inv_dir / "i2vgen-xl" / "clipA"
 
