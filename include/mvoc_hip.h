@@ -43,7 +43,7 @@ typedef struct mvoc_gemm_desc {
   /* operands */
   const void* a;        /* activation source 1 (fp16) */
   const void* a2;       /* optional source 2 for a channel-concat input (cat([x, skip], dim=1)); NULL if none */
-  const void* w;        /* weights [n_pad][k] fp16, k contiguous; for conv k = tap*cin + c (tap-major) */
+  const void* w;        /* weights [n_pad][k] fp16, k contiguous; for conv k = tap*cin + c (tap-major; k_order = 1: chunk-major, below) */
   void* out;            /* [m][ldo] fp16 */
   const void* bias;     /* [n] fp16 or NULL (GEGLU: packed like w rows) */
   const void* rowadd;   /* optional [m / rowadd_div][ld_rowadd] fp16 added per output row (time embedding) */
@@ -113,9 +113,11 @@ typedef struct mvoc_gemm_desc {
                            the nine (three) taps of one 64-channel slab of the source are consumed back to back, so the re-reads a block
                            makes of its own pixel rows (each source line is read once per tap: F.conv2d at pnp_utils.py:939, 968, conv3d at
                            :1042-1057) are ~50 KB apart instead of a whole tap's cin * 256 rows and hit the XCD's L2.  Same products, same
-                           fp32 sums in another order (exact on integer operands).  Needs cin, c1 multiples of 64, no upsample, and the
-                           eight-phase tiles (m >= 1024, 16-byte addressable operands < 2 GB): anything else is an error (-2), not a
-                           fall-back -- the caller holds the tap-major weights for those launches. */
+                           fp32 sums in another order (exact on integer operands).  A form of the 320-WIDE eight-phase tile (it runs on that
+                           tile whatever `tile` says): n a multiple of 320, cin, c1 multiples of 64, conv stride 1 / pad 1 on a
+                           same-size source or temporal3, no upsample, no activation, no LayerNorm fold, no split-K, m >= 1024, 16-byte
+                           addressable operands < 2 GB: anything else is an error (-2), not a fall-back -- the caller holds the
+                           tap-major weights for those launches. */
 } mvoc_gemm_desc;
 
 int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream);

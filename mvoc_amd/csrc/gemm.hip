@@ -983,11 +983,14 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
                      // the folded-upsample instantiation carries the plain epilogue only (gemm8.hip: launch8)
                      (!d->upsample || (d->act == MVOC_ACT_NONE && !d->ln_rowsum));
   if (d->k_order) {
-    MVOC_REQUIRE(d->k_order == 1 && d->a_mode != MVOC_A_PLAIN && !d->upsample && g8_ok && d->m >= 1024 && (tile == 0 || tile == 81 || tile == 82) &&
-                     d->k == (d->a_mode == MVOC_A_CONV3X3 ? 9 : 3) * (int64_t)d->cin,
-                 -2, "gemm: k_order = 1 (chunk-major K) is a conv3x3 / temporal3 form of the eight-phase tiles: cin, c1 %% 64 == 0, no "
-                     "upsample, m >= 1024, 16-byte addressable operands < 2 GB");
+    MVOC_REQUIRE(d->k_order == 1 && d->a_mode != MVOC_A_PLAIN && !d->upsample && g8_ok && d->m >= 1024 && (tile == 0 || tile == 82) &&
+                     d->k == (d->a_mode == MVOC_A_CONV3X3 ? 9 : 3) * (int64_t)d->cin && d->n % 320 == 0 && d->act == MVOC_ACT_NONE &&
+                     !d->ln_rowsum && d->split_k <= 1 &&
+                     (d->a_mode != MVOC_A_CONV3X3 || (a.stride == 1 && a.pad == 1 && d->hsrc == d->hout && d->wsrc == d->wout)),
+                 -2, "gemm: k_order = 1 (chunk-major K) is a form of the 320-wide eight-phase tile: conv3x3 (stride 1, pad 1) / temporal3, "
+                     "n %% 320 == 0, cin, c1 %% 64 == 0, no upsample, no activation, no split-K, m >= 1024, 16-byte addressable operands < 2 GB");
     a.korder = 1;
+    tile = 82;
   }
   if (a.subpx) {
     MVOC_REQUIRE(g8_ok, -2, "gemm: the sub-pixel upsample conv runs on the eight-phase tiles only (k, cin %% 64 == 0, 16-byte addressable output)");
@@ -1006,7 +1009,7 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
     };
     const double e81 = eff(256, 1.0);
     const double e82 = (d->act != MVOC_ACT_GEGLU && d->n % 320 == 0) ? eff(320, 0.85) : 0.0;
-    if (e81 >= 0.55 || e82 >= 0.55 || a.korder) {  // (chunk-major weights: these tiles or nothing -- the caller gates on the same model)
+    if (e81 >= 0.55 || e82 >= 0.55) {
       tile = e82 > e81 ? 82 : 81;
     } else if (d->workspace && d->split_k == 0 && !d->ln_rowsum && d->act != MVOC_ACT_GEGLU && d->k >= 3840) {
       // deep K on a grid of 64..190 tiles (the 16x16 / 8x8 levels): K slices bring the grid to one block per CU; measured
@@ -1022,7 +1025,6 @@ extern "C" int mvoc_gemm_f16(const mvoc_gemm_desc* d, void* stream) {
       }
     }
   }
-  if (a.korder && tile != 81 && tile != 82) tile = 81;  // (k < 256: below the automatic choice's floor; still these tiles or nothing)
   if (tile == 0 && glds_ok) {
     // what the eight-phase tiles do not take: grids that fill less than ~55 % of the chip after quantisation, M < 1024, K < 256
     if (d->k <= 640 && d->m > 2048 && !(d->act == MVOC_ACT_GEGLU && d->k > 320 && d->m >= 16384)) {

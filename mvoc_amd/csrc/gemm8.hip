@@ -41,15 +41,6 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef G8_NT_STORE
 #define G8_NT_STORE 1
 #endif
-#ifndef G8_PREFETCH  // (=1: A/B build; G8_PREFETCH_DIST blocks ahead)
-#define G8_PREFETCH 0
-#endif
-#ifndef G8_PREFETCH_DIST
-#define G8_PREFETCH_DIST 256
-#endif
-#ifndef G8_DEAD_SKIP  // (=0: A/B build of the dead-wave-group skip below)
-#define G8_DEAD_SKIP 1
-#endif
 constexpr unsigned G8_OOB = 0x80000000u;  // >= num_records of every resource: the load returns zeros
 __device__ const uint4 g8_zero16 = {0u, 0u, 0u, 0u};
 
@@ -98,7 +89,14 @@ __device__ unsigned long long g8_dbg[32];  // [0, 16): s_memtime (shader clock) 
 // 3 LayerNorm fold + GEGLU; 0 = everything, decided at run time.  The general epilogue is ~11 k instructions, executed once per
 // block and mostly branched over: with the K loop the kernel does not fit the instruction cache, and a pass's arithmetic took
 // 8-10 k ticks (phase stamps) -- as long as four K tiles -- for 64 values per lane; the plain form is 4 k instructions, 3 k ticks.
-template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF, int EPI>
+// KO: K runs (64-channel chunk, tap, 64) instead of (tap, channel) -- mvoc_gemm_desc.k_order = 1 (conv / temporal conv with host-repacked
+//   weights): the tap changes with EVERY K tile, so a block's nine reads of a pixel row's 128-byte slab follow each other within nine
+//   K tiles (~50 KB of other rows in between instead of a whole tap's cin x 256 rows) and hit the XCD's L2.  An instantiation of its
+//   own, of the 320-wide plain-epilogue form only: that form builds its activation offsets at issue time anyway (!YP), so the tap
+//   switch costs it nothing, while the 256-wide form pays 7-18 % for rebuilding its four offset registers per K tile
+//   (profiles/r6/gemm_per_shape_pmc_korder.txt) -- and as a RUN-TIME branch in y_advance the switch cost every instantiation 1.5 %
+//   (the K loop's code placement moved; profiles/r6/gemm8_round6_experiments.txt).
+template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF, int EPI, bool KO = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   constexpr int XQ = XT * 16;            // channels per quadrant (and per wave group per X half-tile)
   constexpr int XH = 2 * XQ;             // rows of an X half-tile
@@ -131,16 +129,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   G8_STAMP(0);
-  // block id -> (m tile, n tile, K slice)
-  auto decode_tile = [&](unsigned bid, unsigned& mtile, unsigned& ntile, int& slice) {
-  const unsigned logical0 = xcd_remap(bid, gridDim.x);
+  const unsigned logical0 = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned logical = g8_udiv(logical0, p.mg_sk, p.sh_sk);
-  slice = (int)(logical0 - logical * (unsigned)p.split_k);
+  const int slice = (int)(logical0 - logical * (unsigned)p.split_k);
   // Tile order inside an XCD's contiguous range of logical ids (xcd_remap): bands of `band` m-tiles, inside a band m fastest.
   // The 32 blocks an XCD runs at a time then form a band x (32 / band) patch of the tile grid and share band activation panels
   // and 32 / band weight panels through the XCD's L2, instead of 32 / n_tiles m-tiles x ALL n-tiles (n fastest: every m-tile of
   // a 20-n-tile GEGLU launch re-streamed all 6.5 MB of weights past the 4 MB L2 -- 715 MB fetched for 105 + 6.5 MB of operands,
   // profiles/r4/pmc_gemm_traffic.json).  band = 1 is the old order.
+  unsigned mtile, ntile;
   if (p.band > 1) {
     const unsigned per = (unsigned)p.band * (unsigned)p.n_tiles;
     const unsigned b_ = g8_udiv(logical, p.mg_band, p.sh_band);
@@ -164,17 +161,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     const unsigned patch = g8_udiv(r_, p.mg_fr, p.sh_fr);
     mtile = vid * per + (r_ - patch * (unsigned)p.frames) * (unsigned)p.tmap_t + patch;
   }
-  };
-  unsigned mtile, ntile;
-  int slice;
-  decode_tile(blockIdx.x, mtile, ntile, slice);
   const int n0 = (int)ntile * BX;
   const int m0 = (int)mtile * 256;
-  // The last n-tile of a launch whose N is not a multiple of BX (N = 640 = 2.5 tiles of 256: every L1 conv / projection of the UNet;
-  // N = 1920): wave group 1 owns channels n0 + BX / 2 .. -- all of them past N.  Its MFMAs would multiply zero rows and take every
-  // second slot of the matrix pipe from group 0's (one wave of each group per SIMD); a DEAD group keeps its staging duties and
-  // every barrier and skips its fragment reads and MFMAs: the block's K tile then costs group 0's four phases plus four short ones.
-  const bool dead = G8_DEAD_SKIP && XT == 4 && n0 + wr * XH >= p.N;
   const int kbeg = slice * p.k_per_split;
   const int nk = p.k_per_split / 64;
   // X pieces of this wave per half-tile (wave-uniform): 2, or 3 / 2 for BX = 320
@@ -301,11 +289,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   }
   if constexpr (AFF) rowoff[0][0] = row_m(0, 0) - (p.a_mode == MVOC_A_CONV3X3 ? p.wsrc + 1 : 0);
   // K position of the NEXT activation tile to issue (both Y halves of a tile are issued from the same position): all scalar
-  // (p.korder, mvoc_gemm_desc.k_order = 1: K = (64-channel chunk, tap, 64) -- the tap changes with EVERY K tile and the channel
-  // chunk every ntaps tiles: a block's nine reads of a pixel row's 128-byte slab follow each other within nine K tiles)
-  const int ntaps = p.a_mode == MVOC_A_CONV3X3 ? 9 : 3;
+  const int ntaps = p.a_mode == MVOC_A_CONV3X3 ? 9 : 3;  // (KO only)
   int ytap, ych0;
-  if (p.korder) {
+  if constexpr (KO) {
     const int ck = kbeg / (ntaps * 64);
     ytap = (kbeg - ck * ntaps * 64) >> 6;
     ych0 = ck * 64;
@@ -354,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     }
   };
   auto y_advance = [&]() {
-    if (p.korder) {
+    if constexpr (KO) {
       yre = true;
       if (++ytap == ntaps) { ytap = 0; ych0 += 64; }
       return;
@@ -395,12 +381,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define G8_RDX(off)                                             \
-  if (!dead) _Pragma("unroll") for (int i = 0; i < XT; ++i) {   \
+  _Pragma("unroll") for (int i = 0; i < XT; ++i) {              \
     xf[i][0] = G8_LDP(xr0, (off) + i * 2048);                   \
     xf[i][1] = G8_LDP(xr1, (off) + i * 2048);                   \
   }
 #define G8_RDY(dst, off)                                        \
-  if (!dead) _Pragma("unroll") for (int j = 0; j < 2; ++j) {    \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {               \
     dst[j][0] = G8_LDP(yr0, (off) + j * 2048);                  \
     dst[j][1] = G8_LDP(yr1, (off) + j * 2048);                  \
   }
@@ -418,12 +404,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
   };
 #define G8_MMA(A, B, YF)                                                                                              \
   do {                                                                                                                \
-    if (!dead) {                                                                                                      \
-      __builtin_amdgcn_s_setprio(1);                                                                                  \
-      _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < XT; ++i)                   \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j) mma(acc[A][B][i][j], xf[i][s], YF[j][s]);                     \
-      __builtin_amdgcn_s_setprio(0);                                                                                  \
-    }                                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < XT; ++i)                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) mma(acc[A][B][i][j], xf[i][s], YF[j][s]);                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
   } while (0)
 
   // in flight behind the per-tile wait: {Yh0, Xh0, Yh1} of the tile after next = 2 + npx + 2 LDS-DMA of this wave
@@ -764,38 +748,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       if (kg == (n >> 2)) *reinterpret_cast<float2*>(ro + (rb * 16 + n) * 2) = float2{dsum[0], sq};
     }
   };
-#if G8_PREFETCH
-  // The prologue of a block is one cold DMA round trip (phase stamps: 6-9 k ticks before the first MFMA, a sixth of a K = 640 block):
-  // the activation rows of a new m tile come from HBM / the Infinity Cache.  Workgroups are dealt to the XCDs round-robin by id and
-  // every CU holds one block, so the block that takes this CU's -- or a neighbour's -- place when it retires is id + 256 (+ the CUs
-  // of the other XCDs); its first two K tiles' activation lines are requested HERE, under this block's epilogue, into the XCD's
-  // L2: one 4-byte LDS-DMA per row and K tile (no register to keep alive; the bytes land in a dead corner of the ring), 32 rows x
-  // 2 K tiles per wave = one instruction.  Speed only: rows are clamped into the source, padding / validity does not matter.
-  auto prefetch_next = [&]() {
-    const unsigned nb = blockIdx.x + G8_PREFETCH_DIST;
-    if (nb >= gridDim.x) return;
-    unsigned mt2, nt2;
-    int sl2;
-    decode_tile(nb, mt2, nt2, sl2);
-    int kk = sl2 * p.k_per_split + (lane >> 5) * 64;   // lanes 32..63: the second K tile
-    if (kk >= (sl2 + 1) * p.k_per_split) kk = sl2 * p.k_per_split;
-    int row = (int)mt2 * 256 + wave * 32 + (lane & 31);
-    int tap = 0, ch = kk;
-    if (p.a_mode != MVOC_A_PLAIN) {
-      const int nt = p.a_mode == MVOC_A_CONV3X3 ? 9 : 3;
-      if (p.korder) { const int ck = kk / (nt * 64); tap = (kk - ck * nt * 64) >> 6; ch = ck * 64; }
-      else { tap = kk / p.cin; ch = kk - tap * p.cin; }
-      if (p.a_mode == MVOC_A_TEMPORAL3) row += (tap - 1) * p.hw;
-      else if (p.stride == 1 && !UPS) row += (tap / 3 - 1) * p.wsrc + (tap % 3 - 1);
-      else return;  // (strided / upsampled sources: a handful of launches per forward)
-    }
-    const int rows_a = p.a_mode == MVOC_A_CONV3X3 ? p.nimg * p.hsrc * p.wsrc : p.M;
-    row = row < 0 ? 0 : (row >= rows_a ? rows_a - 1 : row);
-    const bool second = ch >= p.c1;
-    const half_t* src = (second ? p.a2 : p.a) + (size_t)row * (second ? p.lda2 : p.lda) + (second ? ch - p.c1 : ch);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, G8_LDS(SMEM - 2048 + wave * 256), 4, 0, 0);
-  };
-#endif
   {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -805,10 +757,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
     load_resid(0, r0, 0, XT * 2);  // pass 0's residual chunks fly under pass 0's arithmetic in both forms
     if constexpr (XT == 4) load_resid(1, r1, 0, XT * 2);
     __builtin_amdgcn_sched_barrier(0);
-#if G8_PREFETCH
-    prefetch_next();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     arith(I0{});
     G8_STAMP(6);
     __builtin_amdgcn_sched_barrier(0);  // (320-wide: 160 live accumulators until here)
@@ -853,9 +801,6 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmArgs p) {
       }
     }
   }
-#if G8_PREFETCH
-  g8_wait_vm<0>();  // (the prefetch pieces write LDS: landed before the workgroup gives its LDS back)
-#endif
 #ifdef MVOC_G8_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G8_STAMP(5);
@@ -873,7 +818,7 @@ void g8_magic(unsigned d, unsigned& mg, int& sh) {
   sh = l - 1;
 }
 
-template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF>
+template <int XT, bool RETAIN, bool YP, bool UPS, bool AFF, bool KO = false>
 int launch8(const GemmArgs& a0, hipStream_t s) {
   const int epi = a0.act == MVOC_ACT_NONE ? (a0.ln_s ? (a0.rowadd ? 0 : 2) : 1) : (a0.act == MVOC_ACT_GEGLU && a0.ln_s && XT == 4) ? 3 : 0;
   GemmArgs a = a0;
@@ -905,7 +850,10 @@ int launch8(const GemmArgs& a0, hipStream_t s) {
     mvoc_set_error("gemm8: grid of %ld blocks", nblk);
     return -2;
   }
-  if constexpr (UPS) {
+  if constexpr (KO) {
+    if (epi != 1) return -9;  // (conv / temporal conv: bias, row-add, residual)
+    hipLaunchKernelGGL((gemm8_kernel<XT, RETAIN, YP, UPS, AFF, 1, true>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+  } else if constexpr (UPS) {
     // the folded-upsample form exists with the plain epilogue only (Upsample2D's conv: bias): its other epilogue forms spilled
     // registers once the sub-pixel gather joined it, and no caller has them (gemm.hip sends such a request to the general tiles)
     if (epi != 1) return -9;
@@ -929,6 +877,13 @@ int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s, int* bx_used) {
   int dummy;
   int& used = bx_used ? *bx_used : dummy;
   used = 256;
+  if (a.korder) {  // chunk-major weights are read by ONE instantiation (below); any other route would multiply them in tap-major order
+    const bool aff_ = a.a_mode == MVOC_A_TEMPORAL3 || (a.a_mode == MVOC_A_CONV3X3 && a.stride == 1 && a.pad == 1 && a.hsrc == a.hout && a.wsrc == a.wout);
+    if (!(bx == 320 && aff_ && !a.upsample && a.act == MVOC_ACT_NONE && !a.ln_s)) {
+      mvoc_set_error("gemm8: k_order = 1 needs the 320-wide tile, an affine conv / temporal gather and the plain epilogue");
+      return -2;
+    }
+  }
   if (a.upsample) {  // (rare: the three upsampler convs of a forward) one form serves every width
     if (bx == 256 || bx == 320) return launch8<4, true, true, true, false>(a, s);
   } else {
@@ -939,6 +894,11 @@ int mvoc_launch_gemm8(const GemmArgs& a, int bx, hipStream_t s, int* bx_used) {
       // model) takes the 256-wide tile, which holds every form
       if (a.act != MVOC_ACT_NONE || (a.ln_s && a.rowadd)) return launch8<4, true, true, false, false>(a, s);
       used = 320;
+      if (a.korder) {
+        // chunk-major K (gemm_args.h: korder): the 320-wide plain-epilogue form only -- gemm.hip sends nothing else here
+        if (a.ln_s) return -9;
+        return launch8<5, false, false, false, true, true>(a, s);
+      }
       return launch8<5, false, false, false, true>(a, s);
     }
   }

@@ -163,7 +163,6 @@ def linear(x, w, bias=None, *, x2=None, act=ACT_NONE, resid=None, n_store=0, out
 
 # ---- chunk-major K order of the conv / temporal-conv weights (include/mvoc_hip.h: mvoc_gemm_desc.k_order) -----------------------------------
 K_ORDER_CHUNK = os.environ.get("MVOC_KORDER", "1") != "0"
-K_ORDER_FORCE_256 = False  # tests: a forced tile 81 takes the chunk-major form too (exactness of the 256-wide kernel's path)
 _CHUNK_CACHE = {}
 
 
@@ -211,11 +210,10 @@ def _chunk_ok(d, x, x2, w, out, bias, resid, rowadd, ntaps, rows_a):
             and d.m * out.stride(0) * 2 < lim and (resid is None or d.m * resid.stride(0) * 2 < lim)
             # Measured (profiles/r6/gemm_per_shape_pmc_korder.txt): FETCH falls 3-7 x on every conv (L2 hit rate 52 -> 85-92 %) and the
             # held clock rises; the 320-wide tile, whose activation offsets are formed at issue time anyway, gains (temporal K = 960:
-            # - 8 %); the 256-wide tile pays for rebuilding its four offset registers EVERY K tile with 12-18 % -- so: the 320-wide
-            # tile on an affine gather (the only form launch8 sends to it), nothing else, unless a test forces tile 81
-            and ((d.tile == 82 or (d.tile == 0 and _g8_choice(d.m, w.shape[0], _CONCURRENCY.n) == 82))
-                 and (d.a_mode != A_CONV3X3 or (d.stride == 1 and d.hsrc == d.hout and d.wsrc == d.wout))
-                 or d.tile == 81 and K_ORDER_FORCE_256))
+            # - 7 %); the 256-wide tile paid 7-18 % for rebuilding its four offset registers EVERY K tile -- so the library has the
+            # form for the 320-wide tile on an affine gather only (gemm8.hip: KO)
+            and w.shape[0] % 320 == 0 and (d.tile == 82 or (d.tile == 0 and _g8_choice(d.m, w.shape[0], _CONCURRENCY.n) == 82))
+            and (d.a_mode != A_CONV3X3 or (d.stride == 1 and d.hsrc == d.hout and d.wsrc == d.wout)))
 
 
 SUBPIXEL_MIN_TILES = 200  # the sub-pixel form of Upsample2D + conv needs a grid that fills the chip; under it the 9-tap split-K form

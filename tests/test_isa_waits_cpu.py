@@ -46,9 +46,11 @@ def test_gemm8_counted_waits_match_the_dma_issued(objs):
     XPC = 16 / 20 one-KB pieces of an X half-tile over 8 waves); `wait_tile` leaves {Yh0, Xh0, Yh1} of the tile after next in
     flight: 2 + PX + 2."""
     ks = {n: v for n, v in objs["gemm8"].items() if "gemm8_kernel" in n}
-    assert len(ks) == 8  # 4 epilogue forms of the 256-wide tile, 3 of the 320-wide, the folded-upsample form (plain epilogue only)
+    assert len(ks) == 9  # 4 epilogue forms of the 256-wide tile, 3 of the 320-wide, the folded-upsample form (plain epilogue only),
+    #                      the chunk-major K form of the 320-wide tile (round 6: KO, plain epilogue only)
     for name, ins in ks.items():
-        xt = _targs(name)[0]
+        targs = _targs(name)
+        xt, ko = targs[0], len(targs) > 6 and targs[6] == 1
         xpc = xt * 4                                   # 1 KB pieces per X half-tile
         px = sorted({xpc // 8, -(-xpc // 8)})          # per wave
         a, b = _k_loop(ins, 2 * 4 * xt * 4)            # two K tiles x four phases x (XT x 2 x 2) MFMAs
@@ -57,17 +59,15 @@ def test_gemm8_counted_waits_match_the_dma_issued(objs):
         assert [i.op for i in loop if i.is_vmem and not i.is_lds_dma] == [], name
         assert [i.op for i in pro if i.is_vmem and not i.is_lds_dma] == [], (name, "an ordinary load in the prologue drains the ring")
         n_dma = sum(1 for i in loop if i.is_lds_dma)
-        # static instructions of two K tiles: 2 x (4 Y + 2 x PXmax X) (the 320-wide tile's third piece: an instruction of its own under
-        # a wave-uniform branch since round 6 -- until then hipcc merged the two halves' third pieces into one predicated issue: 18)
-        assert n_dma == {4: 16, 5: 20}[xt], (name, n_dma)
+        # static instructions of two K tiles: 2 x (4 Y + 2 x PXmax X); the 320-wide tile's third piece is one predicated instruction
+        assert n_dma == {4: 16, 5: 18}[xt], (name, n_dma, ko)
         waits = collections.Counter(i.vmcnt() for i in loop if i.vmcnt() is not None)
         want = {0: 2}                                  # (t + 2 == nk: the tail drains) once per K tile body
         for p_ in px:
             want[2 + p_ + 2] = 2
         assert dict(waits) == want, (name, dict(waits), want)
         # prologue: tile 0 complete + {Yh0, Xh0, Yh1} of tile 1 (+ the 256-wide tile's epilogue-table piece), same two waits
-        # (320-wide: 2 x 3 X + 4 Y of tile 0, 2 + 3 + 2 of tile 1 = 17, every piece an instruction of its own)
-        assert sum(1 for i in pro if i.is_lds_dma) == {4: 15, 5: 17}[xt], name
+        assert sum(1 for i in pro if i.is_lds_dma) == {4: 15, 5: 16}[xt], name
         assert sorted(set(i.vmcnt() for i in pro if i.vmcnt() is not None)) == [0] + [2 + p_ + 2 for p_ in px], name
 
 

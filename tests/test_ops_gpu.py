@@ -344,15 +344,14 @@ class _chunk_major:
             seen.append(int(d.k_order))
             return real(d, *a, **kw)
 
-        o._gemm, o.K_ORDER_CHUNK, o.K_ORDER_FORCE_256 = spy, True, True
+        o._gemm, o.K_ORDER_CHUNK = spy, True
         return seen
 
     def __exit__(self, *exc):
         self.ops._gemm, self.ops.K_ORDER_CHUNK = self.saved
-        self.ops.K_ORDER_FORCE_256 = False
 
 
-@pytest.mark.parametrize("tile", [0, 81, 82])
+@pytest.mark.parametrize("tile", [0, 82])
 @pytest.mark.parametrize("case", ["conv640_320", "conv1280+640_640"])
 def test_conv3x3_chunk_major_k_order_exact(ops, case, tile):
     """K = (64-channel chunk, tap, 64) with host-repacked weights (include/mvoc_hip.h: k_order): the same products summed in another
@@ -369,9 +368,10 @@ def test_conv3x3_chunk_major_k_order_exact(ops, case, tile):
     assert torch.equal(out.float().cpu(), ref), f"{case} tile {tile}: {(out.float().cpu() != ref).sum().item()} wrong outputs"
 
 
-@pytest.mark.parametrize("stride,hw", [(2, 32), (1, 24)])
-def test_conv3x3_chunk_major_stride_and_ragged_rows(ops, stride, hw):
-    """the non-affine gather (stride 2: Downsample2D) and an M that is not a multiple of the 256-pixel tile, chunk-major"""
+@pytest.mark.parametrize("stride,hw,want", [(2, 32, 0), (1, 24, 1)])
+def test_conv3x3_chunk_major_gate_and_ragged_rows(ops, stride, hw, want):
+    """the chunk-major form exists for the affine gather of the 320-wide tile: a stride-2 conv (Downsample2D) keeps the tap-major
+    weights (want 0), a stride-1 conv whose M is not a multiple of the 256-pixel tile takes the form (want 1); both exact"""
     from mvoc_amd.unet import pack_conv3x3
     g = torch.Generator().manual_seed(7 + stride)
     n, cin, cout = 5, 128, 320
@@ -382,12 +382,12 @@ def test_conv3x3_chunk_major_stride_and_ragged_rows(ops, stride, hw):
     ref = F.conv2d(x, wt, b, padding=1, stride=stride)
     assert ref.abs().max() < 2048
     with _chunk_major(ops) as seen:
-        out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=hw, wd=hw, stride=stride, n_store=cout, tile=81)
-    assert seen == [1] and (ho, wo) == tuple(ref.shape[2:])
+        out, ho, wo = ops.conv3x3(dev(_nhwc(x)), pack_conv3x3(dev(wt)), dev(b), nimg=n, h=hw, wd=hw, stride=stride, n_store=cout, tile=82)
+    assert seen == [want] and (ho, wo) == tuple(ref.shape[2:])
     assert torch.equal(out.float().cpu(), _nhwc(ref))
 
 
-@pytest.mark.parametrize("tile", [0, 81, 82])
+@pytest.mark.parametrize("tile", [0, 82])
 def test_tconv3_chunk_major_k_order_exact(ops, tile):
     from mvoc_amd.unet import pack_tconv
     test_tconv3_production_tiles_exact(ops, 81)  # (fills the case cache)
@@ -399,8 +399,8 @@ def test_tconv3_chunk_major_k_order_exact(ops, tile):
 
 
 def test_chunk_major_request_outside_the_eight_phase_tiles_is_an_error(ops):
-    """k_order = 1 is a form of the eight-phase tiles: a request they cannot take fails loudly (the library never reads chunk-major
-    weights with a tap-major kernel)"""
+    """k_order = 1 is a form of the 320-wide eight-phase tile: a request it cannot take fails loudly (the library never reads
+    chunk-major weights with a tap-major kernel)"""
     from mvoc_amd._ffi import GemmDesc, lib
     import ctypes as C
     x = torch.zeros(512, 64, dtype=torch.float16, device="cuda")
@@ -410,8 +410,18 @@ def test_chunk_major_request_outside_the_eight_phase_tiles_is_an_error(ops):
     d.a, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.m, d.n, d.k, d.n_store, d.ldo, d.lda, d.c1, d.cin = 512, 64, 576, 64, 64, 64, 64, 64
     d.a_mode, d.nimg, d.hout, d.wout, d.hsrc, d.wsrc, d.stride, d.k_order = 1, 2, 16, 16, 16, 16, 1, 1
-    assert lib.mvoc_gemm_f16(C.byref(d), torch.cuda.current_stream().cuda_stream) == -2  # m < 1024
-    assert b"k_order" in lib.mvoc_last_error()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mvoc_gemm_f16(C.byref(d), st) == -2 and b"k_order" in lib.mvoc_last_error()  # m < 1024, n = 64
+    x = torch.zeros(2048, 64, dtype=torch.float16, device="cuda")
+    w = torch.zeros(320, 576, dtype=torch.float16, device="cuda")
+    out = torch.empty(2048, 320, dtype=torch.float16, device="cuda")
+    d.a, d.w, d.out, d.m, d.n, d.n_store, d.ldo, d.nimg = x.data_ptr(), w.data_ptr(), out.data_ptr(), 2048, 320, 320, 320, 8
+    assert lib.mvoc_gemm_f16(C.byref(d), st) == 0                                           # the form's own shape class
+    d.tile = 81
+    assert lib.mvoc_gemm_f16(C.byref(d), st) == -2 and b"k_order" in lib.mvoc_last_error()  # a forced 256-wide tile
+    d.tile, d.act = 0, 2
+    assert lib.mvoc_gemm_f16(C.byref(d), st) == -2                                          # an activation
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("tile", [81, 82])

@@ -501,7 +501,7 @@ def test_bench_two_rank_protocol(tmp_path):
     box with the gloo backend standing in for RCCL: both ranks build their shard, barrier, time, MAX-reduce, rank 0 prints
     ONE JSON line whose value is the whole-job aggregate (2 shards) with "scaling": "weak" """
     import subprocess
-    env = dict(os.environ, MVOC_BENCH_BACKEND="gloo")
+    env = dict(os.environ, MVOC_BENCH_BACKEND="gloo", MVOC_BENCH_OVERSUBSCRIBE="1")  # (two ranks on this box's one GPU: otherwise refused)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29561", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--frames", "4", "--latent", "32", "--no-roofline", "--no-cpu-baseline"]
