@@ -37,13 +37,10 @@ struct TfArgs {
 
 // (round 6: s_setprio(1) around the 20 MFMAs of a stage -- the wave against its SIMD partner, a wave of the CU's OTHER block in its
 // vector-only epilogue -- moved nothing: 292 -> 294-297 us at batch 5, profiles/r6/tfused_setprio_ab.txt; not kept)
-#ifndef TF_STAGGER
-#define TF_STAGGER 0
-#endif
-#ifndef TF_STAGGER_US
-#define TF_STAGGER_US 25
-#endif
-
+// (round 6, second experiment: the two blocks a CU holds start together and, doing identical work, stay in lockstep -- their activation
+// load + LayerNorm prologues coincide instead of hiding under each other's MFMAs.  Holding half of the FIRST round's blocks back by 12 /
+// 25 us (ids 256..511, every second id, every second group of 8) moved nothing or lost 4 %: 285 us -> 285-298 us at batch 5,
+// profiles/r6/tfused_stagger_ab.txt; not kept)
 template <int N>
 __device__ __forceinline__ void tf_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -76,19 +73,6 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
 #ifdef MVOC_PP_LAB
   unsigned long long tb = 0;
   TF_STAMP(tb);
-#endif
-#if TF_STAGGER
-  // Build-time experiment (round 6): the two blocks a CU holds start together and, doing identical work, stay in lockstep -- their
-  // activation-load + LayerNorm prologues (a fifth of a block's life, no MFMA) coincide instead of hiding under each other's MFMAs.
-  // Hold back half of the FIRST round's blocks by TF_STAGGER_US microseconds (s_memrealtime, 100 MHz).
-  {
-    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
-    const bool late = TF_STAGGER == 1 ? (id >= 256 && id < 512) : TF_STAGGER == 2 ? (id < 512 && ((id >> 3) & 1)) : (id < 512 && (id & 1));
-    if (late) {
-      const unsigned long long t_ = wall_clock64();
-      while (wall_clock64() - t_ < (unsigned long long)TF_STAGGER_US * 100) __builtin_amdgcn_s_sleep(64);
-    }
-  }
 #endif
   const int ppw = 32 >> p.logf;         // pixels per wave
   // LayerNorm-fold vectors in LDS (an ordinary global load next to in-flight LDS-DMA makes hipcc drain vmcnt(0))
