@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the host-side switches of round 5 on the composition and inversion steps (graph replays, no roofline leg)
+# same-box A/B of the host-side switches of rounds 5 and 6 on the composition and inversion steps (graph replays, no roofline leg)
 run() { # label, env...
   local label=$1; shift
   for mix in comp inv; do
@@ -14,6 +14,7 @@ for rep in 1 2; do
   run no-share MVOC_SHARE_CFG_PREFIX=0
   run no-fold  MVOC_GN_FOLD=0
   run no-subpx MVOC_SUBPIXEL=0
+  run no-korder MVOC_KORDER=0
   run xs-resid MVOC_XS_RESID_TILED_ROWS=0
-  run all-off  MVOC_PRUNE_SOURCE_TAIL=0 MVOC_SHARE_CFG_PREFIX=0 MVOC_GN_FOLD=0 MVOC_SUBPIXEL=0 MVOC_GN_NT_BYTES=99999999999
+  run all-off  MVOC_PRUNE_SOURCE_TAIL=0 MVOC_SHARE_CFG_PREFIX=0 MVOC_GN_FOLD=0 MVOC_SUBPIXEL=0 MVOC_KORDER=0 MVOC_GN_NT_BYTES=99999999999
 done
