@@ -264,3 +264,25 @@ def test_g8_reference_conditioning_layout(golden_dir):
             assert torch.equal(ie[b, f], seeded(300 + base + f, (1, D))[0])
     assert not ie[3].any()
     assert torch.equal(torch.from_numpy(g["comp_fps"][0]), torch.tensor([8] * 5))
+
+
+def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
+    """Build container only (skipped wherever /root/reference is absent, e.g. on the GPU box): tools/gen_golden.py -- which IMPORTS the
+    reference's own pnp_utils.py / pipeline_i2vgen_xl.py / utils.py -- regenerates every fixture under tests/golden/ into a scratch
+    directory, and each file must come out byte for byte as committed: the golden vectors are outputs of the reference's code, not of
+    the oracle's, and nobody edited them."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/i2vgen-xl"):
+        pytest.skip("the reference checkout is not present here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVOC_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "gen_golden.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith((".npz", ".json")))
+    assert made, "gen_golden.py wrote nothing"
+    gold = os.path.join(repo, "tests", "golden")
+    committed = sorted(f for f in os.listdir(gold) if f.endswith((".npz", ".json")))
+    assert made == committed, (made, committed)
+    for f in made:
+        assert open(os.path.join(tmp_path, f), "rb").read() == open(os.path.join(gold, f), "rb").read(), f"{f} differs from the committed fixture"

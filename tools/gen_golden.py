@@ -27,7 +27,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("MVOC_GOLDEN_OUT") or os.path.join(REPO, "tests", "golden")  # (override: tests/test_oracle_golden.py regenerates into a scratch dir)
 sys.path.insert(0, REPO)
 
 from oracle import unet_ref as U  # noqa: E402
