@@ -155,14 +155,15 @@ typedef struct mvoc_attn_desc {
    * the conditional chunk; only their v differ).  NULL: plain attention.  Results equal two plain calls bit for bit. */
   const void* v2;
   void* out2;
+  /* kernel choice of THIS call (head_dim 64, no causal mask): 0 by key count (the software-pipelined kernel from 2 048 keys up), 1 the
+   * phase kernel always, 2 the pipelined kernel wherever it applies.  Speed only -- both kernels return the same bits (the tests
+   * compare them).  Replaces round 4's process-wide setter (flash_pipelined): the library keeps no mutable state between calls
+   * (MVOC_FLASH3=0|1 in the environment changes the default of 0 at load time, for diagnostics). */
+  int32_t pipelined;
 } mvoc_attn_desc;
 
 /* spatial self-attention and image/text cross-attention (flash-style, K/V tiles LDS-staged) */
 int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream);
-/* Kernel choice of the calls that follow (head_dim 64, no causal mask): -1 by key count (default: the software-pipelined kernel from
- * 2 048 keys up), 0 never, 1 wherever it applies.  Process-wide; speed only -- both kernels return the same bits (the tests
- * compare them).  Also settable at load time: MVOC_FLASH3=0|1. */
-void mvoc_flash_pipelined(int mode);
 /* temporal self-attention: one sequence per (sample, pixel), tq == tk == frames <= 32; "t" walks frames
  * (ts = H*W*C for the canonical layout), "b" walks sample*pixel via (b / hw)*bs + (b % hw)*ps */
 typedef struct mvoc_tattn_desc {

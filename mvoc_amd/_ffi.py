@@ -37,7 +37,7 @@ class AttnDesc(C.Structure):
                 ("q_bs", i64), ("q_ts", i64), ("k_bs", i64), ("k_ts", i64), ("v_bs", i64), ("v_ts", i64),
                 ("o_bs", i64), ("o_ts", i64),
                 ("nbatch", i32), ("heads", i32), ("tq", i32), ("tk", i32), ("kv_bdiv", i32),
-                ("head_dim", i32), ("causal", i32), ("scale", C.c_float), ("v2", vp), ("out2", vp)]
+                ("head_dim", i32), ("causal", i32), ("scale", C.c_float), ("v2", vp), ("out2", vp), ("pipelined", i32)]
 
 
 class TAttnDesc(C.Structure):
@@ -80,7 +80,6 @@ SIGNATURES = {
     "mvoc_gemm_row_moments_written": (i32, []),
     "mvoc_row_stats_from_moments_f32": (i32, [vp, i64, i32, i32, i32, f32, vp, vp]),
     "mvoc_flash_attn_f16": (i32, [C.POINTER(AttnDesc), vp]),
-    "mvoc_flash_pipelined": (None, [i32]),
     "mvoc_temporal_attn_f16": (i32, [C.POINTER(TAttnDesc), vp]),
     "mvoc_temporal_qkv_attn_f16": (i32, [C.POINTER(TFusedDesc), vp]),
     "mvoc_xs_linear_f16": (i32, [C.POINTER(XsDesc), vp]),

@@ -18,8 +18,6 @@
 //   Same transposed-score scheme with a single 32x32 tile; V^T goes through a 4 KB wave-private LDS image.
 #include <stdlib.h>
 
-#include <atomic>
-
 #include "common.h"
 
 namespace {
@@ -735,9 +733,9 @@ __global__ __launch_bounds__(256) void tattn_kernel(const TAttnArgs p) {
 
 }  // namespace
 
-// -1: by key count (default), 0: flash_kernel always, 1: flash3_kernel wherever it applies (head dim 64, no causal mask)
-static std::atomic<int> g_f3_mode{getenv("MVOC_FLASH3") ? atoi(getenv("MVOC_FLASH3")) : -1};
-extern "C" void mvoc_flash_pipelined(int mode) { g_f3_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+// load-time default of the kernel choice (diagnostics; read once, never written): MVOC_FLASH3 = 0 flash_kernel always, 1 flash3_kernel wherever
+// it applies (head dim 64, no causal mask); unset: by key count.  Per call: mvoc_attn_desc.pipelined.
+static const int g_f3_env = getenv("MVOC_FLASH3") ? atoi(getenv("MVOC_FLASH3")) : -1;
 
 extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   MVOC_REQUIRE(d && d->q && d->k && d->v && d->out, -1, "flash_attn: null operand");
@@ -764,8 +762,9 @@ extern "C" int mvoc_flash_attn_f16(const mvoc_attn_desc* d, void* stream) {
   dim3 grid((unsigned)nblk);
   a.v2_off = a.o2_off = 0;
   // long key rows of the UNet's self-attention: the software-pipelined kernel (same results bit for bit; +1.5-4 % from 3 600 keys
-  // up, -3 % at 1 024: same-box A/B, profiles/r4/flash3_ab.txt); mvoc_flash_pipelined() / MVOC_FLASH3=0 / 1 force one kernel
-  const int f3_mode = g_f3_mode.load(std::memory_order_relaxed);
+  // up, -3 % at 1 024: same-box A/B, profiles/r4/flash3_ab.txt); mvoc_attn_desc.pipelined (per call) / MVOC_FLASH3=0 / 1 force one kernel
+  MVOC_REQUIRE(d->pipelined >= 0 && d->pipelined <= 2, -1, "flash_attn: pipelined must be 0 (by key count), 1 (never) or 2 (wherever it applies)");
+  const int f3_mode = d->pipelined ? d->pipelined - 1 : g_f3_env;
   const bool pipelined = hd == 64 && !d->causal && (f3_mode >= 0 ? f3_mode != 0 : d->tk >= 2048);
   if (d->v2) {
     MVOC_REQUIRE(d->out2 && hd == 64, -2, "flash_attn: the paired form needs out2 and head_dim 64");

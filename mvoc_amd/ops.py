@@ -288,9 +288,18 @@ def tconv3(x, w, bias, *, nvid, frames, hw, resid=None, out=None, tile=0, split_
     return out
 
 
+class _FlashMode(threading.local):
+    field = 0
+
+
+_FLASH_MODE = _FlashMode()
+
+
 def flash_pipelined(mode):
-    """kernel choice behind flash_attn (include/mvoc_hip.h: mvoc_flash_pipelined): -1 by key count, 0 / 1 force; same bits either way"""
-    lib.mvoc_flash_pipelined(int(mode))
+    """kernel choice of the flash_attn calls THIS thread makes from now on (passed per call as ``mvoc_attn_desc.pipelined``; the library
+    itself keeps no such state): -1 by key count (default), 0 the phase kernel always, 1 the software-pipelined kernel wherever it
+    applies; same bits either way"""
+    _FLASH_MODE.field = {-1: 0, 0: 1, 1: 2}[int(mode)]
 
 
 def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=64, causal=False, scale=0.0, v2=None, out2=None):
@@ -311,6 +320,7 @@ def flash_attn(q, k, v, *, nbatch, heads, tq, tk, kv_bdiv=1, out=None, head_dim=
     d.q_bs, d.k_bs, d.v_bs, d.o_bs = tq * d.q_ts, tk * d.k_ts, tk * d.v_ts, tq * d.o_ts
     d.nbatch, d.heads, d.tq, d.tk, d.kv_bdiv = nbatch, heads, tq, tk, kv_bdiv
     d.head_dim, d.causal, d.scale = head_dim, int(bool(causal)), scale
+    d.pipelined = _FLASH_MODE.field
     check(lib.mvoc_flash_attn_f16(C.byref(d), _stream()), "flash_attn")
     return out
 
