@@ -128,25 +128,48 @@ __global__ __launch_bounds__(NW * 64) void tfused_kernel(const TfArgs p) {
   }
   s1 += __shfl_xor(s1, 32);
   const float mu = s1 / (float)C;
-  // second pass over the register-resident row: sum of squared deviations (as F.layer_norm; E[x^2] - mu^2 cancels for rows
-  // whose mean is large against their spread)
+  // second pass over the register-resident row: the moments of x - c with c the mean rounded to fp16, in PACKED fp16 (the difference of
+  // two nearby fp16 values is exact up to half an ulp of the small difference; v_dot2 accumulates in fp32) -- as xslin.hip's LayerNorm
+  // fold; E[x^2] - mu^2 cancels for rows whose mean is large against their spread, and the fp32 form of this pass (convert, subtract,
+  // fma per element: 480 vector instructions per wave, 640 more for the normalisation below) was a third of the prologue that the
+  // CU's other block has to hide (round 6)
+  float q2 = 0.f;
+  {
+    const half_t c16 = (half_t)mu;
+    const half2_t c2 = {c16, c16};
 #pragma unroll
-  for (int s = 0; s < NK; ++s)
+    for (int s = 0; s < NK; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dv = (float)xf[s][e] - mu;
-      s2 = __builtin_fmaf(dv, dv, s2);
-    }
-  s2 += __shfl_xor(s2, 32);
-  const float rs = rsqrtf(s2 / (float)C + p.eps);
-  // normalise the row in place, once: x^ = (x - mean) * rstd in fp16.  gamma rides on the weights (W' = W * gamma) and beta in the
+      for (int e = 0; e < 4; ++e) {
+        const half2_t v2 = {xf[s][2 * e], xf[s][2 * e + 1]};
+        const half2_t d2 = v2 - c2;
+        q2 = __builtin_amdgcn_fdot2(d2, d2, q2, false);
+      }
+    q2 += __shfl_xor(q2, 32);
+    const float dm = mu - (float)c16;  // mean of x - c (at most half an fp16 ulp of the mean): known without a pass of its own
+    s2 = fmaxf(q2 / (float)C - dm * dm, 0.f);
+  }
+  const float rs = rsqrtf(s2 + p.eps);
+  // normalise the row in place, once: x^ = (x - mean) * rstd as ONE fused multiply-add per element with fp16 input and output
+  // (v_fma_mixlo / mixhi_f16: x * rstd - mean * rstd in fp32, rounded once).  gamma rides on the weights (W' = W * gamma) and beta in the
   // per-channel constant c = beta @ W^T, so a projection tile's fix-up is ONE add per value -- no row-sum correction, no
   // per-row statistics in the epilogues (the earlier rstd * (acc - mean * rowsum) + c form cost ~1000 cycles per stage beside
   // the partner's MFMAs)
+  const float nb = -mu * rs;
 #pragma unroll
-  for (int s = 0; s < NK; ++s)
+  for (int s = 0; s < NK; ++s) {
+    // (written out: hipcc turns the C form into convert / packed fp32 fma / convert, twice the instructions)
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ w = __builtin_bit_cast(u32x4_, xf[s]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xf[s][e] = (half_t)(((float)xf[s][e] - mu) * rs);
+    for (int d = 0; d < 4; ++d) {
+      unsigned o;
+      asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+          : "=&v"(o) : "v"(w[d]), "v"(rs), "v"(nb));
+      w[d] = o;
+    }
+    xf[s] = __builtin_bit_cast(half8_t, w);
+  }
 
   // The two waves of a SIMD (wave w and w + 4) run ONE BARRIER APART: while one multiplies a stage (20 MFMAs on registers and
   // LDS fragments), its partner does the previous stage's LayerNorm fix-up / softmax / stores (VALU, LDS, VMEM) -- matrix pipe
