@@ -558,7 +558,10 @@ def visible_gpus_without_hip():
     the *_VISIBLE_DEVICES lists the runtime would apply"""
     import glob
     n = 0
-    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None  # (no KFD topology in this container's sysfs: the caller falls back to the runtime's own count)
+    for f in nodes:
         try:
             props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
         except OSError:
@@ -581,6 +584,8 @@ def self_launch(args):
     n = args.gpus
     if not args.selftest_launch:
         visible = visible_gpus_without_hip()
+        if visible is None:  # sysfs tells nothing here: ask the runtime (on builds without amdsmi this initialises HIP in this parent,
+            visible = torch.cuda.device_count()  # which starts children and never replaces itself -- within this pool's rule)
         if n > visible and os.environ.get("MVOC_BENCH_OVERSUBSCRIBE") != "1":  # (the one-GPU test box runs two ranks on its GPU)
             raise SystemExit(f"bench.py: --gpus {n} but only {visible} device(s) visible")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
