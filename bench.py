@@ -665,7 +665,9 @@ def main():
     if dist is not None:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
-        keys = {(i["uuid"] or i["pci"] or f"index-{i['device_index']}") for i in idents}
+        # (one node: two ranks share a GPU iff they report the same device index; the bus address / uuid ride along as evidence and
+        # would separate two nodes -- a runtime that reports one uuid for every device must not make a valid run look oversubscribed)
+        keys = {(i["device_index"], i["pci"] or i["uuid"]) for i in idents}
         if len(keys) != world and os.environ.get("MVOC_BENCH_OVERSUBSCRIBE") != "1":
             raise SystemExit(f"bench.py: {world} ranks on {len(keys)} distinct device(s): {idents}")
 
